@@ -1,0 +1,259 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY; runs ONLY in the build container (needs /root/reference).
+
+Generates tests/golden/*.npz by RUNNING THE IMPORTED REFERENCE (oracle/ref_import.py) on seeded inputs:
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+Fixtures hold data only (inputs, logged random draws, expected outputs).  Weights are NOT stored: they
+are regenerated from oracle.genpose_oracle.make_state_dict(seed, mode) (reference key names; loaded into
+the reference nets with load_state_dict(strict=True), which also pins the key schema / shapes).
+
+What each file pins:
+  g1_g2_ops.npz   FPS idx (3 levels) and ball-query idx (6 calls) through the reference's own autograd
+                  Functions (pointnet2_utils.py) - backed by the C restatement, see pn2_ops.c header.
+  g3_encoder.npz  Pointnet2ClsMSG(0) forward, BN stats randomised.
+  g4_g5_nets.npz  PoseScoreNet / PoseEnergyNet at t in {1e-5, 0.15, 0.55, 1.0}.
+  g6_ode.npz      PoseNet.pred_func with the ODE sampler (T0 1.0 / 0.55, sampling_steps None / 20, warm start).
+  g7_pc.npz       PoseNet.pred_func with the PC sampler, 20 steps, logged randn_like draws.
+  g8_rank.npz     get_energy + sort_poses_by_energy + sort_sRT_by_energy(ratio=.6,'average').
+  g9_track.npz    3-frame tracking loop semantics (evaluation_tracking.py:262-337) incl. add_noise_to_RT draws.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import genpose_oracle as go
+from . import ref_import
+from genpose_amd import synth
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+class DrawLog:
+    """Logs every torch.randn / torch.randn_like result while active (call order preserved)."""
+
+    def __init__(self):
+        self.draws = []
+
+    def __enter__(self):
+        self._randn, self._randn_like = torch.randn, torch.randn_like
+        log = self.draws
+
+        def randn(*a, **k):
+            r = self._randn(*a, **k)
+            log.append(r.detach().clone())
+            return r
+
+        def randn_like(x, **k):
+            r = self._randn_like(x, **k)
+            log.append(r.detach().clone())
+            return r
+
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._randn, self._randn_like
+
+
+def make_agent(ns, mode, seed=0, sampler="ode", sampling_steps=None):
+    import argparse
+    cfg = argparse.Namespace(**vars(ns.cfg))
+    cfg.posenet_mode = mode
+    cfg.sampler_mode = [sampler]
+    cfg.sampling_steps = sampling_steps
+    agent = ns.PoseNet(cfg)
+    sd = go.make_state_dict(seed, mode)
+    agent.net.load_state_dict(sd, strict=True)
+    agent.net.eval()
+    return agent, sd
+
+
+def score_time_log(agent):
+    """Wrap the score net so every evaluation's t is recorded."""
+    times = []
+    net = agent.net.pose_score_net
+    orig = net.forward
+
+    def fwd(data, *a, **k):
+        times.append(float(data["t"][0, 0]))
+        return orig(data, *a, **k)
+
+    net.forward = fwd
+    return times, lambda: setattr(net, "forward", orig)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = ref_import.load()
+    torch.set_grad_enabled(False)
+    P = ns.pn2_utils
+
+    # ---------------- G1/G2
+    clouds = synth.golden_clouds()  # [4,1024,3]: 2 surface-like, 1 tiled-duplicate, 1 grid ties
+    xyz = torch.from_numpy(clouds)
+    g = {"clouds": clouds}
+    cur = xyz
+    for lvl, (npnt, radii, nss) in enumerate(zip([512, 256, 128], go.LIGHT_CFG["radii"], go.LIGHT_CFG["nsamples"])):
+        idx = P.furthest_point_sample(cur.contiguous(), npnt)
+        new = P.gather_operation(cur.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+        g[f"fps_idx{lvl}"] = idx.numpy().astype(np.int16)
+        for s, (r, nsmp) in enumerate(zip(radii, nss)):
+            bq = P.ball_query(r, nsmp, cur.contiguous(), new).numpy()
+            g[f"bq{lvl}_{s}_cloud0"] = bq[0].astype(np.int16)
+            g[f"bq{lvl}_{s}_sha"] = np.array([sha(bq[b].astype(np.int32)) for b in range(bq.shape[0])])
+        cur = new
+    # odd sizes: n not a power of two, tiny nsample
+    odd = torch.from_numpy(synth.golden_clouds(seed=77)[:2, :700].copy())
+    g["odd_clouds"] = odd.numpy()
+    g["odd_fps"] = P.furthest_point_sample(odd.contiguous(), 100).numpy().astype(np.int16)
+    g["odd_bq"] = P.ball_query(0.05, 5, odd.contiguous(), odd[:, :50].contiguous()).numpy().astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, "g1_g2_ops.npz"), **g)
+
+    # ---------------- G3 encoder
+    agent, sd = make_agent(ns, "score")
+    feat = agent.net({"pts": xyz}, mode="pts_feature")
+    # per-level features for cloud 0 through forward hooks on the SA modules
+    inter = []
+    hooks = [m.register_forward_hook(lambda m, i, o: inter.append(o)) for m in agent.net.pts_encoder.SA_modules]
+    agent.net({"pts": xyz[:1]}, mode="pts_feature")
+    for h in hooks:
+        h.remove()
+    g3 = {"clouds": clouds, "feat": feat.numpy(), "seed": np.array(0)}
+    for lvl in range(3):
+        nx, f = inter[lvl]
+        g3[f"new_xyz{lvl}"] = nx[0].numpy()
+        g3[f"feat{lvl}_first32"] = f[0, :, :32].numpy()  # [C, 32 points]
+    np.savez_compressed(os.path.join(OUT, "g3_encoder.npz"), **g3)
+
+    # ---------------- G4/G5 nets
+    gen = torch.Generator().manual_seed(11)
+    pf = torch.randn(8, 1024, generator=gen).abs()
+    pose = torch.randn(8, 9, generator=gen)
+    g4 = {"pts_feat": pf.numpy(), "pose": pose.numpy(), "t": np.array([1e-5, 0.15, 0.55, 1.0], dtype=np.float32)}
+    e_agent, sd_e = make_agent(ns, "energy")
+    for i, t in enumerate(g4["t"]):
+        tt = torch.ones(8, 1) * float(t)
+        data = {"pts_feat": pf, "sampled_pose": pose, "t": tt}
+        g4[f"score_{i}"] = agent.net(data, mode="score").numpy()
+        g4[f"energy_{i}"] = e_agent.net(data, mode="energy").numpy()
+    np.savez_compressed(os.path.join(OUT, "g4_g5_nets.npz"), **g4)
+
+    # ---------------- G6 ODE sampler (B=2, K=10)
+    pts2 = xyz[:2].clone()
+    cen2 = pts2.mean(dim=1)
+    g6 = {"pts": pts2.numpy(), "K": np.array(10)}
+    cases = [("T1_none", 1.0, None, False), ("T055_none", 0.55, None, False), ("T055_s20", 0.55, 20, False),
+             ("T015_warm", 0.15, None, True)]
+    for name, T0, steps, warm in cases:
+        ag, _ = make_agent(ns, "score", sampler="ode", sampling_steps=steps)
+        times, restore = score_time_log(ag)
+        init_x = None
+        if warm:
+            gi = torch.Generator().manual_seed(5)
+            r6 = go.normalize_rotation(torch.randn(2, 6, generator=gi))
+            init_x = torch.cat([r6, 0.02 * torch.randn(2, 3, generator=gi)], dim=-1)
+            g6[f"{name}_init_x"] = init_x.numpy()
+        torch.manual_seed(100)
+        with DrawLog() as dl:
+            data = {"pts": pts2.clone(), "pts_center": cen2.clone()}
+            pred, proc = ag.pred_func(data, repeat_num=10, save_path=None, T0=T0, init_x=init_x, return_process=True)
+        restore()
+        assert len(dl.draws) == 1
+        g6[f"{name}_prior_noise"] = dl.draws[0].numpy()  # standard normal [20,9] (before * sigma(T0))
+        g6[f"{name}_pred"] = pred.numpy()
+        g6[f"{name}_proc_shape"] = np.array(proc.shape)
+        g6[f"{name}_proc_last3"] = proc[:, :, -3:].numpy()
+        g6[f"{name}_proc_first2"] = proc[:, :, :2].numpy()
+        g6[f"{name}_eval_t"] = np.array(times)
+        g6[f"{name}_T0"] = np.array(T0)
+        g6[f"{name}_steps"] = np.array(-1 if steps is None else steps)
+    np.savez_compressed(os.path.join(OUT, "g6_ode.npz"), **g6)
+
+    # ---------------- G7 PC sampler, 20 steps
+    ag, _ = make_agent(ns, "score", sampler="pc", sampling_steps=20)
+    torch.manual_seed(200)
+    with DrawLog() as dl:
+        data = {"pts": pts2.clone(), "pts_center": cen2.clone()}
+        pred, proc = ag.pred_func(data, repeat_num=10, save_path=None, return_process=True)
+    assert len(dl.draws) == 41
+    g7 = {"pts": pts2.numpy(), "prior_noise": dl.draws[0].numpy(),
+          "z_langevin": torch.stack(dl.draws[1::2]).numpy(), "z_predictor": torch.stack(dl.draws[2::2]).numpy(),
+          "pred": pred.numpy(), "proc": proc.numpy()}
+    np.savez_compressed(os.path.join(OUT, "g7_pc.npz"), **g7)
+
+    # ---------------- G8 energy + ranking + aggregation (on the T055_none ODE poses)
+    pred = torch.from_numpy(g6["T055_none_pred"])
+    data = {"pts": pts2.clone(), "pts_center": cen2.clone()}
+    energy = e_agent.get_energy(data=data, pose_samples=pred, T=1e-5)
+    sorted_pose, sorted_energy = ns.sort_poses_by_energy(pred, energy)
+    RT_sorted = go.pose9_to_RT(sorted_pose)  # evaluation_single.py:345-352 (get_rot_matrix is the shimmed pytorch3d)
+    RT_unsorted = go.pose9_to_RT(pred)
+    # evaluation path (sgpa_utils.py:897-954) re-sorts the *unsorted* hypotheses by energy on the host;
+    # its .cuda() call is redirected to CPU for this run only.
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sel, avg_sRT, sel_e = ns.sgpa.sort_sRT_by_energy(RT_unsorted.copy(), energy.numpy(), ranker="energy_ranker", ratio=0.6,
+                                                     error_mode="average")
+    del torch.Tensor.cuda
+    g8 = {"pts": pts2.numpy(), "pred": pred.numpy(), "energy": energy.numpy(), "sorted_pose": sorted_pose.numpy(),
+          "sorted_energy": sorted_energy.numpy(), "RT_sorted": RT_sorted, "selected_sRT": sel, "average_sRT": avg_sRT,
+          "selected_energy": sel_e}
+    np.savez_compressed(os.path.join(OUT, "g8_rank.npz"), **g8)
+
+    # ---------------- G9 tracking: 3 frames, 2 objects, warm start from previous average (evaluation_tracking.py:262-337)
+    ag, _ = make_agent(ns, "score", sampler="ode", sampling_steps=None)
+    frames = synth.golden_tracking_frames()  # [3,2,1024,3]
+    gt = synth.golden_tracking_gt()  # [2,4,4] float32
+    g9 = {"frames": frames, "gt_RT": gt}
+    torch.manual_seed(300)
+    prev = None
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for fi in range(frames.shape[0]):
+        pts = torch.from_numpy(frames[fi])
+        cen = pts.mean(dim=1)
+        with DrawLog() as dl:
+            init_RT = ns.tracking.add_noise_to_RT(torch.from_numpy(gt))  # drawn every frame (:302), then overwritten
+            if prev is not None:
+                init_RT = prev.clone()
+            init_x = torch.cat([init_RT[:, :3, 0], init_RT[:, :3, 1], init_RT[:, :3, 3] - cen], dim=-1).float()
+            data = {"pts": pts.clone(), "pts_center": cen.clone()}
+            pred = ag.pred_func(data, repeat_num=10, save_path=None, T0=0.15, init_x=init_x)
+        energy = e_agent.get_energy(data={"pts": pts.clone(), "pts_center": cen.clone()}, pose_samples=pred, T=1e-5)
+        sp, se = ns.sort_poses_by_energy(pred, energy)
+        RTs = go.pose9_to_RT(sp)
+        avg = _cal_average(ns, RTs, max(1, int(0.6 * 10)))
+        g9[f"f{fi}_init_x"] = init_x.numpy()
+        g9[f"f{fi}_prior_noise"] = dl.draws[-1].numpy()
+        for di in range(4):  # add_noise_to_RT draws: theta [B], quaternion [B,4], norm [B], direction [B,3]
+            g9[f"f{fi}_noise_draw{di}"] = dl.draws[di].numpy()
+        g9[f"f{fi}_n_draws"] = np.array(len(dl.draws))
+        g9[f"f{fi}_pred"] = pred.numpy()
+        g9[f"f{fi}_energy"] = energy.numpy()
+        g9[f"f{fi}_avg_sRT"] = avg.numpy()
+        prev = avg
+    del torch.Tensor.cuda
+    np.savez_compressed(os.path.join(OUT, "g9_track.npz"), **g9)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+def _cal_average(ns, RTs, sel):
+    """cal_average_sRT (evaluation_tracking.py:60-77) lives in a runner module that cannot be imported
+    (module-level get_config/makedirs/.cuda side effects); its body is the same sequence of
+    reference/pytorch3d calls as sort_sRT_by_energy's 'average' tail, which IS importable - use that."""
+    e = np.zeros(RTs.shape[:2] + (2,))
+    e[:, :, :] = -np.arange(RTs.shape[1])[None, :, None]  # already sorted: keep order
+    _, avg, _ = ns.sgpa.sort_sRT_by_energy(RTs.copy(), e, ranker="energy_ranker", ratio=sel / RTs.shape[1] + 1e-9,
+                                           error_mode="average")
+    return torch.from_numpy(avg).float()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,189 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/pn2_ops.c header).
+
+ctypes binding of oracle/build/libpn2_oracle.so: numpy-in / numpy-out CPU versions of the
+reference's `pointnet2_cuda` kernels.  Also exposes `as_pointnet2_cuda_module()`, a CPU object
+with the 9 pybind names of pointnet2_api.cpp:10-24 operating in place on CPU torch tensors, which
+the import shim (oracle/ref_import.py) installs as `pointnet2_cuda` so that the reference's own
+Python can run in the build container.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "build", "libpn2_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pn2_ops.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def opt_n_threads(n):
+    return lib().gpo_opt_n_threads(int(n))
+
+
+def furthest_point_sampling(xyz, m, temp=None):
+    """xyz (B,N,3) f32 -> idx (B,m) i32; temp (B,N) starts at 1e10 (pointnet2_utils.py:27)."""
+    xyz, px = _f(xyz)
+    B, N, _ = xyz.shape
+    if temp is None:
+        temp = np.full((B, N), 1e10, dtype=np.float32)
+    temp, pt = _f(temp)
+    idx = np.zeros((B, m), dtype=np.int32)
+    lib().gpo_furthest_point_sampling(B, N, int(m), px, pt, idx.ctypes.data_as(ctypes.c_void_p))
+    return idx, temp
+
+
+def gather_points(points, idx):
+    """points (B,C,N), idx (B,M) -> (B,C,M)"""
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    B, C, N = points.shape
+    M = idx.shape[1]
+    out = np.empty((B, C, M), dtype=np.float32)
+    lib().gpo_gather_points(B, C, N, M, pp, pi, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample) i32 (pre-zeroed as pointnet2_utils.py:219)."""
+    xyz, px = _f(xyz)
+    new_xyz, pn = _f(new_xyz)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = np.zeros((B, M, nsample), dtype=np.int32)
+    lib().gpo_ball_query(B, N, M, ctypes.c_float(radius), int(nsample), pn, px, idx.ctypes.data_as(ctypes.c_void_p))
+    return idx
+
+
+def group_points(points, idx):
+    """points (B,C,N), idx (B,np,ns) -> (B,C,np,ns)"""
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    B, C, N = points.shape
+    _, npnt, ns = idx.shape
+    out = np.empty((B, C, npnt, ns), dtype=np.float32)
+    lib().gpo_group_points(B, C, N, npnt, ns, pp, pi, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def three_nn(unknown, known):
+    unknown, pu = _f(unknown)
+    known, pk = _f(known)
+    B, N, _ = unknown.shape
+    M = known.shape[1]
+    d = np.empty((B, N, 3), dtype=np.float32)
+    i = np.empty((B, N, 3), dtype=np.int32)
+    lib().gpo_three_nn(B, N, M, pu, pk, d.ctypes.data_as(ctypes.c_void_p), i.ctypes.data_as(ctypes.c_void_p))
+    return d, i
+
+
+def three_interpolate(points, idx, weight):
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    B, C, M = points.shape
+    N = idx.shape[1]
+    out = np.empty((B, C, N), dtype=np.float32)
+    lib().gpo_three_interpolate(B, C, M, N, pp, pi, pw, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    B, C, npnt, ns = grad_out.shape
+    out = np.zeros((B, C, n), dtype=np.float32)
+    lib().gpo_group_points_grad(B, C, n, npnt, ns, pg, pi, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    B, C, M = grad_out.shape
+    out = np.zeros((B, C, n), dtype=np.float32)
+    lib().gpo_gather_points_grad(B, C, n, M, pg, pi, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    B, C, N = grad_out.shape
+    out = np.zeros((B, C, m), dtype=np.float32)
+    lib().gpo_three_interpolate_grad(B, C, N, m, pg, pi, pw, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+class _Pointnet2CudaCPU:
+    """CPU object with the pybind surface of pointnet2_api.cpp:10-24 (in-place on CPU torch tensors)."""
+
+    @staticmethod
+    def _p(t):
+        assert t.is_contiguous()
+        return ctypes.c_void_p(t.data_ptr())
+
+    def furthest_point_sampling_wrapper(self, b, n, m, points, temp, idx):
+        lib().gpo_furthest_point_sampling(b, n, m, self._p(points), self._p(temp), self._p(idx))
+        return 1
+
+    def gather_points_wrapper(self, b, c, n, npoints, points, idx, out):
+        lib().gpo_gather_points(b, c, n, npoints, self._p(points), self._p(idx), self._p(out))
+        return 1
+
+    def ball_query_wrapper(self, b, n, m, radius, nsample, new_xyz, xyz, idx):
+        lib().gpo_ball_query(b, n, m, ctypes.c_float(radius), nsample, self._p(new_xyz), self._p(xyz), self._p(idx))
+        return 1
+
+    def group_points_wrapper(self, b, c, n, npoints, nsample, points, idx, out):
+        lib().gpo_group_points(b, c, n, npoints, nsample, self._p(points), self._p(idx), self._p(out))
+        return 1
+
+    def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
+        lib().gpo_three_nn(b, n, m, self._p(unknown), self._p(known), self._p(dist2), self._p(idx))
+        return 1
+
+    def three_interpolate_wrapper(self, b, c, m, n, points, idx, weight, out):
+        lib().gpo_three_interpolate(b, c, m, n, self._p(points), self._p(idx), self._p(weight), self._p(out))
+
+    def group_points_grad_wrapper(self, b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        lib().gpo_group_points_grad(b, c, n, npoints, nsample, self._p(grad_out), self._p(idx), self._p(grad_points))
+        return 1
+
+    def gather_points_grad_wrapper(self, b, c, n, npoints, grad_out, idx, grad_points):
+        lib().gpo_gather_points_grad(b, c, n, npoints, self._p(grad_out), self._p(idx), self._p(grad_points))
+        return 1
+
+    def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight, grad_points):
+        lib().gpo_three_interpolate_grad(b, c, n, m, self._p(grad_out), self._p(idx), self._p(weight), self._p(grad_points))
+
+
+def as_pointnet2_cuda_module():
+    return _Pointnet2CudaCPU()

@@ -1,0 +1,156 @@
+"""CPU: the oracle restatement (oracle/genpose_oracle.py + oracle/pn2_ops.c) against the golden vectors
+captured from the imported reference (oracle/gen_golden.py).  This is what pins the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import genpose_oracle as go
+from oracle import pn2_oracle as ops
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def sd_score():
+    return go.make_state_dict(0, "score")
+
+
+@pytest.fixture(scope="module")
+def sd_energy():
+    return go.make_state_dict(0, "energy")
+
+
+def test_g1_g2_ops(golden):
+    g = golden("g1_g2_ops.npz")
+    cur = g["clouds"]
+    for lvl, npnt in enumerate([512, 256, 128]):
+        idx, _ = ops.furthest_point_sampling(cur, npnt)
+        assert np.array_equal(idx, g[f"fps_idx{lvl}"].astype(np.int32))
+        assert np.all(idx[:, 0] == 0)
+        new = ops.gather_points(np.ascontiguousarray(cur.transpose(0, 2, 1)), idx).transpose(0, 2, 1)
+        new = np.ascontiguousarray(new)
+        for s in range(2):
+            bq = ops.ball_query(go.LIGHT_CFG["radii"][lvl][s], go.LIGHT_CFG["nsamples"][lvl][s], cur, new)
+            assert np.array_equal(bq[0], g[f"bq{lvl}_{s}_cloud0"].astype(np.int32))
+            assert [sha(bq[b]) for b in range(bq.shape[0])] == list(g[f"bq{lvl}_{s}_sha"])
+        cur = new
+    odd = g["odd_clouds"]
+    assert np.array_equal(ops.furthest_point_sampling(odd, 100)[0], g["odd_fps"])
+    assert np.array_equal(ops.ball_query(0.05, 5, odd, np.ascontiguousarray(odd[:, :50])), g["odd_bq"])
+
+
+def test_fps_tie_rule_is_bit_reversal():
+    """among equal maxima the slot with the smallest bit-reversed index wins (S=4: {1,2} -> 2)."""
+    p = np.array([[[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0.5, 0, 0]]], dtype=np.float32)
+    assert ops.furthest_point_sampling(p, 3)[0].tolist() == [[0, 2, 1]]
+    # 8 identical far points: winner order follows bit reversal of the slot
+    q = np.zeros((1, 8, 3), dtype=np.float32)
+    q[0, 1:] = [3, 0, 0]
+    assert ops.furthest_point_sampling(q, 2)[0].tolist() == [[0, 4]]
+
+
+def test_g3_encoder(golden, sd_score):
+    g = golden("g3_encoder.npz")
+    feat, inter = go.encoder_forward(sd_score, torch.from_numpy(g["clouds"]), return_intermediates=True)
+    np.testing.assert_allclose(feat.numpy(), g["feat"], rtol=1e-5, atol=1e-5)
+    for lvl in range(3):
+        np.testing.assert_array_equal(inter[lvl]["new_xyz"][0], g[f"new_xyz{lvl}"])
+        np.testing.assert_allclose(inter[lvl]["features"][0][:, :32], g[f"feat{lvl}_first32"], rtol=1e-5, atol=1e-5)
+
+
+def test_g4_g5_nets(golden, sd_score, sd_energy):
+    g = golden("g4_g5_nets.npz")
+    pf, pose = torch.from_numpy(g["pts_feat"]), torch.from_numpy(g["pose"])
+    for i, t in enumerate(g["t"]):
+        tt = torch.ones(8, 1) * float(t)
+        s = go.score_forward(sd_score, pf, pose, tt).numpy()
+        e = go.energy_forward(sd_energy, pf, pose, tt).numpy()
+        np.testing.assert_allclose(s, g[f"score_{i}"], rtol=1e-5, atol=1e-6 * np.abs(g[f"score_{i}"]).max())
+        np.testing.assert_allclose(e, g[f"energy_{i}"], rtol=1e-5, atol=1e-6 * np.abs(g[f"energy_{i}"]).max())
+    assert np.abs(g["score_0"]).max() > 1.0  # de-zeroed output layers: the score is not identically 0
+
+
+@pytest.mark.parametrize("case", ["T1_none", "T055_none", "T055_s20", "T015_warm"])
+def test_g6_ode(golden, sd_score, case):
+    g = golden("g6_ode.npz")
+    pts = torch.from_numpy(g["pts"])
+    steps = int(g[f"{case}_steps"])
+    init_x = torch.from_numpy(g[f"{case}_init_x"]) if f"{case}_init_x" in g else None
+    log = []
+    pred, proc, nfev = go.pred_func(sd_score, pts, pts.mean(dim=1), 10, "ode", torch.from_numpy(g[f"{case}_prior_noise"]),
+                                    T0=float(g[f"{case}_T0"]), sampling_steps=None if steps < 0 else steps,
+                                    init_x=init_x, log=log)
+    ref_t = g[f"{case}_eval_t"]
+    assert nfev == len(ref_t) == 3 + 6 * len(log)  # App. A.4: NFE = 3 + 6 * attempts
+    assert pred.dtype == torch.float64
+    np.testing.assert_allclose(pred.numpy(), g[f"{case}_pred"], rtol=1e-6, atol=1e-6)
+    assert list(proc.shape) == list(g[f"{case}_proc_shape"])
+    np.testing.assert_allclose(proc[:, :, -3:].numpy(), g[f"{case}_proc_last3"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(proc[:, :, :2].numpy(), g[f"{case}_proc_first2"], rtol=1e-6, atol=1e-5)
+
+
+def test_g7_pc(golden, sd_score):
+    g = golden("g7_pc.npz")
+    pts = torch.from_numpy(g["pts"])
+    pred, proc, _ = go.pred_func(sd_score, pts, pts.mean(dim=1), 10, "pc", torch.from_numpy(g["prior_noise"]),
+                                 sampling_steps=20, z_langevin=torch.from_numpy(g["z_langevin"]),
+                                 z_predictor=torch.from_numpy(g["z_predictor"]))
+    assert pred.dtype == torch.float32
+    np.testing.assert_allclose(pred.numpy(), g["pred"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(proc.numpy(), g["proc"], rtol=1e-4, atol=2e-3)
+
+
+def test_g8_rank_aggregate(golden, sd_energy):
+    g = golden("g8_rank.npz")
+    pts = torch.from_numpy(g["pts"])
+    pred = torch.from_numpy(g["pred"])
+    energy = go.get_energy(sd_energy, pts, pts.mean(dim=1), pred, T=1e-5)
+    np.testing.assert_allclose(energy.numpy(), g["energy"], rtol=1e-4, atol=1e-5 * np.abs(g["energy"]).max())
+    sp, se = go.sort_poses_by_energy(pred, torch.from_numpy(g["energy"]))
+    np.testing.assert_array_equal(sp.numpy(), g["sorted_pose"])
+    np.testing.assert_array_equal(se.numpy(), g["sorted_energy"])
+    RT = go.pose9_to_RT(sp)
+    np.testing.assert_allclose(RT, g["RT_sorted"], atol=1e-12)
+    np.testing.assert_allclose(RT[:, :6], g["selected_sRT"], atol=1e-12)  # host re-sort == device sort (no ties)
+    avg, _ = go.aggregate_sorted(RT, ratio=0.6)
+    np.testing.assert_allclose(avg, g["average_sRT"], atol=1e-6)
+
+
+def test_g9_tracking(golden, sd_score, sd_energy):
+    g = golden("g9_track.npz")
+    prev = None
+    for fi in range(g["frames"].shape[0]):
+        pts = torch.from_numpy(g["frames"][fi])
+        cen = pts.mean(dim=1)
+        init_x = torch.from_numpy(g[f"f{fi}_init_x"])
+        if prev is not None:  # warm start = previous frame's aggregated pose (evaluation_tracking.py:302-310)
+            mine = torch.cat([prev[:, :3, 0], prev[:, :3, 1], prev[:, :3, 3] - cen], dim=-1).float()
+            np.testing.assert_allclose(mine.numpy(), init_x.numpy(), atol=1e-6)
+        pred, _, _ = go.pred_func(sd_score, pts, cen, 10, "ode", torch.from_numpy(g[f"f{fi}_prior_noise"]), T0=0.15, init_x=init_x)
+        np.testing.assert_allclose(pred.numpy(), g[f"f{fi}_pred"], rtol=1e-6, atol=1e-6)
+        energy = go.get_energy(sd_energy, pts, cen, pred, T=1e-5)
+        np.testing.assert_allclose(energy.numpy(), g[f"f{fi}_energy"], rtol=1e-4, atol=1e-5 * np.abs(g[f"f{fi}_energy"]).max())
+        sp, _ = go.sort_poses_by_energy(pred, torch.from_numpy(g[f"f{fi}_energy"]))
+        avg, _ = go.aggregate_sorted(go.pose9_to_RT(sp), ratio=0.6)
+        np.testing.assert_allclose(avg, g[f"f{fi}_avg_sRT"], atol=1e-5)
+        prev = torch.from_numpy(avg)
+
+
+def test_rk45_matches_scipy():
+    """oracle.rk45_solve restates scipy's RK45; same f -> same steps, states and nfev (both directions, with t_eval)."""
+    from scipy.integrate import solve_ivp
+
+    def f(t, y):
+        return np.array([y[1], -y[0] * (1 + 0.3 * np.sin(3 * t)), -0.5 * y[2] + np.cos(t)])
+
+    y0 = np.array([1.0, 0.0, 0.3])
+    for (t0, t1, te) in [(0.0, 5.0, None), (1.0, 1e-5, None), (0.55, 1e-5, np.linspace(0.55, 1e-5, 17))]:
+        ref = solve_ivp(f, (t0, t1), y0, rtol=1e-5, atol=1e-5, method="RK45", t_eval=te)
+        ts, ys, nfev = go.rk45_solve(f, t0, y0, t1, t_eval=te)
+        assert nfev == ref.nfev
+        np.testing.assert_allclose(ts, ref.t, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(ys, ref.y, rtol=1e-13, atol=1e-14)
