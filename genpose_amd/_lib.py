@@ -1,0 +1,122 @@
+"""ctypes binding of libgenpose_hip.so (the C ABI of include/genpose_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, the caller gets an exception.
+`lib()` only dlopens (safe without a GPU); `check_device()` verifies the device is gfx950.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libgenpose_hip.so")
+
+c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
+P = c_void_p
+
+
+class GpScoreNet(ctypes.Structure):
+    """struct gp_scorenet (include/genpose_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ("w_pose0", "b_pose0", "w_pose2", "b_pose2", "w_headx", "w_out", "b_out", "fourier_w",
+                                        "w_t1", "b_t1", "w_headt", "w_headp", "b_head")]
+
+
+NETP = ctypes.POINTER(GpScoreNet)
+
+# name -> argtypes ; every function returns int (0 ok / negative GP_E*), except gp_pack_weight_size (int64)
+SIGNATURES = {
+    "gp_version": [],
+    "gp_device_arch": [ctypes.c_char_p, c_int],
+    "gp_furthest_point_sampling": [c_int, c_int, c_int, P, P, P, P],
+    "gp_gather_points": [c_int, c_int, c_int, c_int, P, P, P, P],
+    "gp_gather_points_grad": [c_int, c_int, c_int, c_int, P, P, P, P],
+    "gp_ball_query": [c_int, c_int, c_int, c_float, c_int, P, P, P, P],
+    "gp_group_points": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
+    "gp_group_points_grad": [c_int, c_int, c_int, c_int, c_int, P, P, P, P],
+    "gp_three_nn": [c_int, c_int, c_int, P, P, P, P, P],
+    "gp_three_interpolate": [c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "gp_three_interpolate_grad": [c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "gp_fps_chain": [c_int, c_int, c_int, ctypes.POINTER(c_int), P, P, P, P, P, P, P, P],
+    "gp_ball_query_msg": [c_int, c_int, c_int, c_float, c_int, c_float, c_int, P, P, P, P, P],
+    "gp_sa_mlp_max": [c_int] * 8 + [P] * 10 + [P, c_int, c_int, P],
+    "gp_pack_weight_size": [c_int, c_int],
+    "gp_pack_weight": [c_int, c_int, P, c_int, P],
+    "gp_score_tile_rows": [],
+    "gp_cloud_embed": [c_int, NETP, P, P, P],
+    "gp_time_embed": [c_int, NETP, P, P, P],
+    "gp_score_eval": [c_int, c_int, NETP, P, P, P, P, c_int, P, P],
+    "gp_pc_step": [c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
+    "gp_rk45_state_bytes": [],
+    "gp_rk45_state_layout": [ctypes.POINTER(c_int64), c_int],
+    "gp_rk45_phase": [c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
+    "gp_rank_aggregate": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
+}
+OPTIONAL = set()
+
+_lib = None
+
+
+class GenposeHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise GenposeHipError(
+                f"{SO_PATH} is missing - build it with `python -m genpose_amd.build` (hipcc, gfx950). "
+                "genpose_amd has no CPU fallback.")
+        l = ctypes.CDLL(SO_PATH)
+        for name, args in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                if name in OPTIONAL:
+                    continue
+                raise GenposeHipError(f"{SO_PATH} does not export {name} (stale build?)")
+            fn.argtypes = args
+            fn.restype = c_int64 if name in ("gp_pack_weight_size", "gp_rk45_state_bytes") else c_int
+        _lib = l
+    return _lib
+
+
+_ERR = {-1: "GP_EINVAL (bad size / null pointer / unsupported shape)", -2: "GP_ELAUNCH (HIP launch failed)",
+        -3: "GP_EARCH (device is not gfx950)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GenposeHipError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+_device_checked = False
+
+
+def check_device():
+    """Raise unless the current HIP device is gfx950 (MI355X)."""
+    global _device_checked
+    if _device_checked:
+        return
+    buf = ctypes.create_string_buffer(64)
+    rc = lib().gp_device_arch(buf, 64)
+    if rc != 0:
+        raise GenposeHipError(f"genpose_amd needs an MI355X (gfx950) device; found '{buf.value.decode()}' ({_ERR.get(rc, rc)})")
+    _device_checked = True
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous torch tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,21 @@
+"""The subset of the reference's flat argparse namespace (configs/config.py:4-112) the inference hot path reads,
+with the reference's defaults.  `get_config(**overrides)` returns an argparse.Namespace, so code written against the
+reference's `cfg` object works unchanged; the reference's own namespace can be passed to PoseNet(cfg) directly."""
+import argparse
+
+DEFAULTS = dict(
+    device="cuda", num_points=1024, pose_mode="rot_matrix", pts_encoder="pointnet2", pointnet2_params="light",
+    posenet_mode="score", regression_head="Rx_Ry_and_T", sde_mode="ve", sampler_mode=["ode"], sampling_steps=None,
+    energy_mode="IP", s_theta_mode="score", norm_energy="identical", eval_repeat_num=50, batch_size=192, T0=1.0,
+    pooling_mode="nearest", ranker="energy_ranker", score_model_dir="", energy_model_dir="", result_dir="", test_source="Real",
+    save_video=False, is_train=False, use_pretrain=False, log_dir="debug", parallel=False, seed=0,
+)
+
+
+def get_config(**overrides):
+    d = dict(DEFAULTS)
+    unknown = set(overrides) - set(d)
+    if unknown:
+        raise ValueError(f"unknown config fields: {sorted(unknown)}")
+    d.update(overrides)
+    return argparse.Namespace(**d)

@@ -1,0 +1,578 @@
+// PointNet++ grouping operators for gfx950 (MI355X): FPS, ball query, gather, group, three-NN, interpolate.
+// Replaces the reference's CUDA extension `pointnet2_cuda`
+// (networks/pts_encoder/pointnet2_utils/pointnet2/src/*.cu) behind the C ABI of include/genpose_hip.h.
+//
+// Design (wave64, LDS-staged):
+//  * FPS: one 256-thread workgroup per cloud, coordinates and running min-distances live in registers,
+//    the cloud is mirrored in LDS only for the broadcast read of the last selected point; argmax is a
+//    packed-key max (distance bits | tie rank) -> 6 DPP/shuffle steps per wave + one LDS exchange and
+//    ONE barrier per selected point.  The tie rank reproduces the reference's shared-memory tree
+//    (sampling_gpu.cu:86-91,143-203): smallest bit-reversed slot wins.
+//  * ball query: one wave per centre, 64 candidates per step, ballot + prefix popcount keeps index order.
+//  * distances: the FMA chain nvcc emits for dx*dx+dy*dy+dz*dz, spelled with
+//    __fmaf_rn/__fmul_rn so hipcc cannot re-associate or re-contract it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/genpose_hip.h"
+#include "gp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+}
+
+// order-preserving float -> uint (total order on non-NaN floats)
+__device__ __forceinline__ uint32_t fkey(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+constexpr int FPS_T = 256;       // threads per cloud
+constexpr int FPS_MAXPPT = 16;   // register-resident points per thread (n <= 4096)
+
+struct FpsRank {
+    int S, logS, Q;
+    // rank of element k: larger = preferred among equal distances.
+    //  in-thread (same k % S): first strict maximum = smaller k wins  (sampling_gpu.cu:124-138)
+    //  across threads: lower slot wins at every tree level = smaller bit-reversed slot wins (:86-91,143-203)
+    __device__ __forceinline__ uint32_t rank(int k) const {
+        uint32_t slot = (uint32_t)k & (uint32_t)(S - 1);
+        uint32_t br = logS ? (__brev(slot) >> (32 - logS)) : 0u;
+        return (uint32_t)(S - 1 - (int)br) * (uint32_t)Q + (uint32_t)(Q - 1 - (k >> logS));
+    }
+    __device__ __forceinline__ int unrank(uint32_t r) const {
+        uint32_t a = r / (uint32_t)Q, bq = r - a * (uint32_t)Q;
+        uint32_t br = (uint32_t)(S - 1) - a;
+        uint32_t slot = logS ? (__brev(br) >> (32 - logS)) : 0u;
+        return (int)(((uint32_t)(Q - 1) - bq) << logS | slot);
+    }
+};
+
+__device__ __forceinline__ FpsRank make_rank(int n) {
+    // opt_n_threads (cuda_utils.h:10-14): S = min(2^floor(log2 n), 1024)
+    int lg = 31 - __clz(n);
+    if (lg > 10) lg = 10;
+    FpsRank r;
+    r.logS = lg;
+    r.S = 1 << lg;
+    r.Q = (n + r.S - 1) >> lg;
+    return r;
+}
+
+// One FPS pass over the n points held in LDS (sx/sy/sz) selecting m of them.
+// temp_io: optional global running-min buffer (API semantics) - read at start, written back at the end.
+template <int PPT>
+__device__ void fps_pass(int n, int m, const float *sx, const float *sy, const float *sz, float *temp_io,
+                         int32_t *idx_out, unsigned long long (*slots)[FPS_T / 64]) {
+    const int tid = threadIdx.x;
+    const FpsRank rk = make_rank(n);
+    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+    uint32_t rnk[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        int k = tid + j * FPS_T;
+        bool ok = k < n;
+        px[j] = ok ? sx[k] : 0.f;
+        py[j] = ok ? sy[k] : 0.f;
+        pz[j] = ok ? sz[k] : 0.f;
+        tmp[j] = ok ? (temp_io ? temp_io[k] : 1e10f) : 0.f;
+        rnk[j] = ok ? rk.rank(k) : 0u;
+    }
+    int old = 0;
+    if (tid == 0) idx_out[0] = 0;
+    for (int it = 1; it < m; ++it) {
+        float x1 = sx[old], y1 = sy[old], z1 = sz[old];
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            int k = tid + j * FPS_T;
+            if (k < n) {
+                float d = sqdist(px[j], py[j], pz[j], x1, y1, z1);
+                float d2 = fminf(d, tmp[j]);
+                tmp[j] = d2;
+                unsigned long long key = ((unsigned long long)fkey(d2) << 32) | rnk[j];
+                best = key > best ? key : best;
+            }
+        }
+        best = wave_max_u64(best);
+        const int par = it & 1;
+        if ((tid & 63) == 0) slots[par][tid >> 6] = best;
+        __syncthreads();
+        unsigned long long v = slots[par][0];
+#pragma unroll
+        for (int w = 1; w < FPS_T / 64; ++w) {
+            unsigned long long o = slots[par][w];
+            v = o > v ? o : v;
+        }
+        old = rk.unrank((uint32_t)(v & 0xffffffffull));
+        if (tid == 0) idx_out[it] = old;
+    }
+    if (temp_io) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            int k = tid + j * FPS_T;
+            if (k < n) temp_io[k] = tmp[j];
+        }
+    }
+}
+
+// Fallback for n > FPS_T*FPS_MAXPPT: running min kept in global memory (temp must be provided).
+__device__ void fps_pass_big(int n, int m, const float *xyz, float *temp, int32_t *idx_out,
+                             unsigned long long (*slots)[FPS_T / 64]) {
+    const int tid = threadIdx.x;
+    const FpsRank rk = make_rank(n);
+    int old = 0;
+    if (tid == 0) idx_out[0] = 0;
+    for (int it = 1; it < m; ++it) {
+        float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+        unsigned long long best = 0ull;
+        for (int k = tid; k < n; k += FPS_T) {
+            float d = sqdist(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], x1, y1, z1);
+            float d2 = fminf(d, temp[k]);
+            temp[k] = d2;
+            unsigned long long key = ((unsigned long long)fkey(d2) << 32) | rk.rank(k);
+            best = key > best ? key : best;
+        }
+        best = wave_max_u64(best);
+        const int par = it & 1;
+        if ((tid & 63) == 0) slots[par][tid >> 6] = best;
+        __syncthreads();
+        unsigned long long v = slots[par][0];
+#pragma unroll
+        for (int w = 1; w < FPS_T / 64; ++w) {
+            unsigned long long o = slots[par][w];
+            v = o > v ? o : v;
+        }
+        old = rk.unrank((uint32_t)(v & 0xffffffffull));
+        if (tid == 0) idx_out[it] = old;
+    }
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_T) void fps_kernel(int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
+                                                    int32_t *__restrict__ idx) {
+    extern __shared__ float lds[];  // sx[n] sy[n] sz[n]
+    __shared__ unsigned long long slots[2][FPS_T / 64];
+    const int b = blockIdx.x;
+    xyz += (size_t)b * n * 3;
+    temp += (size_t)b * n;
+    idx += (size_t)b * m;
+    float *sx = lds, *sy = lds + n, *sz = lds + 2 * n;
+    for (int i = threadIdx.x; i < n * 3; i += FPS_T) {
+        float v = xyz[i];
+        int k = i / 3, c = i - k * 3;
+        (c == 0 ? sx : c == 1 ? sy : sz)[k] = v;
+    }
+    __syncthreads();
+    fps_pass<PPT>(n, m, sx, sy, sz, temp, idx, slots);
+}
+
+__global__ __launch_bounds__(FPS_T) void fps_big_kernel(int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
+                                                        int32_t *__restrict__ idx) {
+    __shared__ unsigned long long slots[2][FPS_T / 64];
+    const int b = blockIdx.x;
+    fps_pass_big(n, m, xyz + (size_t)b * n * 3, temp + (size_t)b * n, idx + (size_t)b * m, slots);
+}
+
+// FPS + gather for up to three consecutive levels (encoder path): n0 <= 1024.
+struct FpsChainArgs {
+    int n0, nlevels;
+    int m[3];
+    const float *xyz;
+    int32_t *idx[3];
+    float *new_xyz[3];
+};
+
+__global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
+    __shared__ float cur[2][3][1024];
+    __shared__ int32_t sel[1024];
+    __shared__ unsigned long long slots[2][FPS_T / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *xyz = a.xyz + (size_t)b * a.n0 * 3;
+    for (int i = tid; i < a.n0 * 3; i += FPS_T) {
+        int k = i / 3, c = i - k * 3;
+        cur[0][c][k] = xyz[i];
+    }
+    __syncthreads();
+    int n = a.n0, buf = 0;
+    for (int l = 0; l < a.nlevels; ++l) {
+        const int m = a.m[l];
+        float *sx = cur[buf][0], *sy = cur[buf][1], *sz = cur[buf][2];
+        if (n <= FPS_T)
+            fps_pass<1>(n, m, sx, sy, sz, nullptr, sel, slots);
+        else if (n <= 2 * FPS_T)
+            fps_pass<2>(n, m, sx, sy, sz, nullptr, sel, slots);
+        else
+            fps_pass<4>(n, m, sx, sy, sz, nullptr, sel, slots);
+        __syncthreads();
+        int32_t *gi = a.idx[l] + (size_t)b * m;
+        float *gx = a.new_xyz[l] + (size_t)b * m * 3;
+        for (int j = tid; j < m; j += FPS_T) {
+            int s = sel[j];
+            float x = sx[s], y = sy[s], z = sz[s];
+            gi[j] = s;
+            gx[j * 3 + 0] = x;
+            gx[j * 3 + 1] = y;
+            gx[j * 3 + 2] = z;
+            cur[buf ^ 1][0][j] = x;
+            cur[buf ^ 1][1][j] = y;
+            cur[buf ^ 1][2][j] = z;
+        }
+        __syncthreads();
+        n = m;
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- ball query
+constexpr int BQ_T = 256;
+constexpr int BQ_CPW = 4;  // centres per wave
+
+// One wave scans the cloud in index order, 64 candidates per step.  NS = number of scales (1 or 2).
+template <int NS, bool ZERO_FILL>
+__global__ __launch_bounds__(BQ_T) void ball_query_kernel(int n, int m, float r0, int ns0, float r1, int ns1,
+                                                          const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                                                          int32_t *__restrict__ idx0, int32_t *__restrict__ idx1) {
+    extern __shared__ float lds[];  // sx[n] sy[n] sz[n]
+    const int b = blockIdx.y;
+    xyz += (size_t)b * n * 3;
+    float *sx = lds, *sy = lds + n, *sz = lds + 2 * n;
+    for (int i = threadIdx.x; i < n * 3; i += BQ_T) {
+        int k = i / 3, c = i - k * 3;
+        (c == 0 ? sx : c == 1 ? sy : sz)[k] = xyz[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float rr0 = __fmul_rn(r0, r0), rr1 = __fmul_rn(r1, r1);  // ball_query_gpu.cu:23 (f32)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int ci = 0; ci < BQ_CPW; ++ci) {
+        const int p = (blockIdx.x * (BQ_T / 64) + wave) * BQ_CPW + ci;
+        if (p >= m) break;
+        const float *c = new_xyz + ((size_t)b * m + p) * 3;
+        const float cx = c[0], cy = c[1], cz = c[2];
+        int32_t *o0 = idx0 + ((size_t)b * m + p) * ns0;
+        int32_t *o1 = NS > 1 ? idx1 + ((size_t)b * m + p) * ns1 : nullptr;
+        int cnt0 = 0, cnt1 = 0, first0 = 0, first1 = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            float d2 = 3.0e38f;
+            if (k < n) d2 = sqdist(cx, cy, cz, sx[k], sy[k], sz[k]);
+            if (cnt0 < ns0) {
+                unsigned long long mk = __ballot(k < n && d2 < rr0);
+                if (mk) {
+                    if (cnt0 == 0) first0 = base + __ffsll((long long)mk) - 1;
+                    int slot = cnt0 + __popcll(mk & below);
+                    if (((mk >> lane) & 1ull) && slot < ns0) o0[slot] = k;
+                    cnt0 += __popcll(mk);
+                }
+            }
+            if (NS > 1 && cnt1 < ns1) {
+                unsigned long long mk = __ballot(k < n && d2 < rr1);
+                if (mk) {
+                    if (cnt1 == 0) first1 = base + __ffsll((long long)mk) - 1;
+                    int slot = cnt1 + __popcll(mk & below);
+                    if (((mk >> lane) & 1ull) && slot < ns1) o1[slot] = k;
+                    cnt1 += __popcll(mk);
+                }
+            }
+            if (cnt0 >= ns0 && (NS == 1 || cnt1 >= ns1)) break;
+        }
+        // first hit pre-fills every slot (ball_query_gpu.cu:35-39); no hit: untouched / zero
+        if (cnt0 > 0 || ZERO_FILL) {
+            int v = cnt0 > 0 ? first0 : 0;
+            for (int sl = (cnt0 < ns0 ? cnt0 : ns0) + lane; sl < ns0; sl += 64) o0[sl] = v;
+        }
+        if (NS > 1 && (cnt1 > 0 || ZERO_FILL)) {
+            int v = cnt1 > 0 ? first1 : 0;
+            for (int sl = (cnt1 < ns1 ? cnt1 : ns1) + lane; sl < ns1; sl += 64) o1[sl] = v;
+        }
+    }
+}
+
+// Large-n fallback (cloud does not fit LDS): candidates straight from global memory (L1/L2 resident).
+__global__ __launch_bounds__(BQ_T) void ball_query_big_kernel(int n, int m, float r0, int ns0, const float *__restrict__ new_xyz,
+                                                              const float *__restrict__ xyz, int32_t *__restrict__ idx0) {
+    const int b = blockIdx.y;
+    xyz += (size_t)b * n * 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float rr0 = __fmul_rn(r0, r0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int p = blockIdx.x * (BQ_T / 64) + wave;
+    if (p >= m) return;
+    const float *c = new_xyz + ((size_t)b * m + p) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    int32_t *o0 = idx0 + ((size_t)b * m + p) * ns0;
+    int cnt0 = 0, first0 = 0;
+    for (int base = 0; base < n && cnt0 < ns0; base += 64) {
+        const int k = base + lane;
+        float d2 = 3.0e38f;
+        if (k < n) d2 = sqdist(cx, cy, cz, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+        unsigned long long mk = __ballot(k < n && d2 < rr0);
+        if (mk) {
+            if (cnt0 == 0) first0 = base + __ffsll((long long)mk) - 1;
+            int slot = cnt0 + __popcll(mk & below);
+            if (((mk >> lane) & 1ull) && slot < ns0) o0[slot] = k;
+            cnt0 += __popcll(mk);
+        }
+    }
+    if (cnt0 > 0)
+        for (int sl = (cnt0 < ns0 ? cnt0 : ns0) + lane; sl < ns0; sl += 64) o0[sl] = first0;
+}
+
+// ---------------------------------------------------------------------------------------------- gather / group
+__global__ void gather_points_kernel(int c, int n, int m, const float *__restrict__ points, const int32_t *__restrict__ idx,
+                                     float *__restrict__ out) {
+    const int b = blockIdx.z, ci = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    out[((size_t)b * c + ci) * m + p] = points[((size_t)b * c + ci) * n + idx[(size_t)b * m + p]];
+}
+
+__global__ void gather_points_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+                                          float *__restrict__ grad_points) {
+    const int b = blockIdx.z, ci = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    atomicAdd(grad_points + ((size_t)b * c + ci) * n + idx[(size_t)b * m + p], grad_out[((size_t)b * c + ci) * m + p]);
+}
+
+__global__ void group_points_kernel(int c, int n, int q, const float *__restrict__ points, const int32_t *__restrict__ idx,
+                                    float *__restrict__ out) {
+    // q = npoints*nsample; one thread per (b, c, q)
+    const int b = blockIdx.z, ci = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q) return;
+    out[((size_t)b * c + ci) * q + i] = points[((size_t)b * c + ci) * n + idx[(size_t)b * q + i]];
+}
+
+__global__ void group_points_grad_kernel(int c, int n, int q, const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+                                         float *__restrict__ grad_points) {
+    const int b = blockIdx.z, ci = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q) return;
+    atomicAdd(grad_points + ((size_t)b * c + ci) * n + idx[(size_t)b * q + i], grad_out[((size_t)b * c + ci) * q + i]);
+}
+
+// ---------------------------------------------------------------------------------------------- three_nn / interpolate
+__global__ void three_nn_kernel(int n, int m, const float *__restrict__ unknown, const float *__restrict__ known,
+                                float *__restrict__ dist2, int32_t *__restrict__ idx) {
+    extern __shared__ float lds[];  // kx[m] ky[m] kz[m] (tiled in chunks of TILE)
+    constexpr int TILE = 2048;
+    const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    known += (size_t)b * m * 3;
+    float ux = 0, uy = 0, uz = 0;
+    if (p < n) {
+        const float *u = unknown + ((size_t)b * n + p) * 3;
+        ux = u[0], uy = u[1], uz = u[2];
+    }
+    // interpolate_gpu.cu:30: doubles initialised to 1e40, compared against the float distance
+    double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+    int b1 = 0, b2 = 0, b3 = 0;
+    float *kx = lds, *ky = lds + TILE, *kz = lds + 2 * TILE;
+    for (int base = 0; base < m; base += TILE) {
+        const int cnt = min(TILE, m - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt * 3; i += blockDim.x) {
+            int k = i / 3, c = i - k * 3;
+            (c == 0 ? kx : c == 1 ? ky : kz)[k] = known[(size_t)base * 3 + i];
+        }
+        __syncthreads();
+        if (p < n) {
+            for (int k = 0; k < cnt; ++k) {
+                double d = (double)sqdist(ux, uy, uz, kx[k], ky[k], kz[k]);
+                int kk = base + k;
+                if (d < best1) {
+                    best3 = best2; b3 = b2;
+                    best2 = best1; b2 = b1;
+                    best1 = d; b1 = kk;
+                } else if (d < best2) {
+                    best3 = best2; b3 = b2;
+                    best2 = d; b2 = kk;
+                } else if (d < best3) {
+                    best3 = d; b3 = kk;
+                }
+            }
+        }
+    }
+    if (p < n) {
+        float *o = dist2 + ((size_t)b * n + p) * 3;
+        int32_t *oi = idx + ((size_t)b * n + p) * 3;
+        o[0] = (float)best1; o[1] = (float)best2; o[2] = (float)best3;
+        oi[0] = b1; oi[1] = b2; oi[2] = b3;
+    }
+}
+
+__global__ void three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points, const int32_t *__restrict__ idx,
+                                         const float *__restrict__ weight, float *__restrict__ out) {
+    const int b = blockIdx.z, ci = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float *w = weight + ((size_t)b * n + p) * 3;
+    const int32_t *id = idx + ((size_t)b * n + p) * 3;
+    const float *src = points + ((size_t)b * c + ci) * m;
+    // nvcc contraction of w0*p0 + w1*p1 + w2*p2 (interpolate_gpu.cu:95)
+    out[((size_t)b * c + ci) * n + p] = __fmaf_rn(w[2], src[id[2]], __fmaf_rn(w[1], src[id[1]], __fmul_rn(w[0], src[id[0]])));
+}
+
+__global__ void three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+                                              const float *__restrict__ weight, float *__restrict__ grad_points) {
+    const int b = blockIdx.z, ci = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float g = grad_out[((size_t)b * c + ci) * n + p];
+    const float *w = weight + ((size_t)b * n + p) * 3;
+    const int32_t *id = idx + ((size_t)b * n + p) * 3;
+    float *gp = grad_points + ((size_t)b * c + ci) * m;
+    atomicAdd(gp + id[0], g * w[0]);
+    atomicAdd(gp + id[1], g * w[1]);
+    atomicAdd(gp + id[2], g * w[2]);
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int gp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, gp_stream_t s) {
+    if (b < 0 || n <= 0 || m < 0 || !xyz || !temp || !idx) return GP_EINVAL;
+    if (b == 0 || m == 0) return GP_OK;
+    if (m > n) return GP_EINVAL;
+    hipStream_t st = (hipStream_t)s;
+    const size_t lds = (size_t)n * 3 * sizeof(float);
+    if (n <= FPS_T)
+        hipLaunchKernelGGL(fps_kernel<1>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+    else if (n <= 2 * FPS_T)
+        hipLaunchKernelGGL(fps_kernel<2>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+    else if (n <= 4 * FPS_T)
+        hipLaunchKernelGGL(fps_kernel<4>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+    else if (n <= 8 * FPS_T)
+        hipLaunchKernelGGL(fps_kernel<8>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+    else if (n <= FPS_MAXPPT * FPS_T)
+        hipLaunchKernelGGL(fps_kernel<FPS_MAXPPT>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+    else
+        hipLaunchKernelGGL(fps_big_kernel, dim3(b), dim3(FPS_T), 0, st, n, m, xyz, temp, idx);
+    return gp_launch_status();
+}
+
+int gp_fps_chain(int b, int n0, int nlevels, const int *m, const float *xyz, int32_t *idx0, float *new_xyz0, int32_t *idx1,
+                 float *new_xyz1, int32_t *idx2, float *new_xyz2, gp_stream_t s) {
+    if (b < 0 || n0 <= 0 || n0 > 1024 || nlevels < 1 || nlevels > 3 || !m || !xyz) return GP_EINVAL;
+    if (b == 0) return GP_OK;
+    FpsChainArgs a;
+    a.n0 = n0;
+    a.nlevels = nlevels;
+    a.xyz = xyz;
+    int32_t *ii[3] = {idx0, idx1, idx2};
+    float *xx[3] = {new_xyz0, new_xyz1, new_xyz2};
+    int prev = n0;
+    for (int l = 0; l < 3; ++l) {
+        a.m[l] = l < nlevels ? m[l] : 0;
+        a.idx[l] = ii[l];
+        a.new_xyz[l] = xx[l];
+        if (l < nlevels) {
+            if (m[l] <= 0 || m[l] > prev || !ii[l] || !xx[l]) return GP_EINVAL;
+            prev = m[l];
+        }
+    }
+    hipLaunchKernelGGL(fps_chain_kernel, dim3(b), dim3(FPS_T), 0, (hipStream_t)s, a);
+    return gp_launch_status();
+}
+
+int gp_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx, gp_stream_t s) {
+    if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || !new_xyz || !xyz || !idx) return GP_EINVAL;
+    if (b == 0 || m == 0) return GP_OK;
+    hipStream_t st = (hipStream_t)s;
+    if ((size_t)n * 12 <= 60 * 1024) {
+        dim3 grid((m + (BQ_T / 64) * BQ_CPW - 1) / ((BQ_T / 64) * BQ_CPW), b);
+        hipLaunchKernelGGL((ball_query_kernel<1, false>), grid, dim3(BQ_T), (size_t)n * 12, st, n, m, radius, nsample, 0.f, 0, new_xyz,
+                           xyz, idx, (int32_t *)nullptr);
+    } else {
+        dim3 grid((m + BQ_T / 64 - 1) / (BQ_T / 64), b);
+        hipLaunchKernelGGL(ball_query_big_kernel, grid, dim3(BQ_T), 0, st, n, m, radius, nsample, new_xyz, xyz, idx);
+    }
+    return gp_launch_status();
+}
+
+int gp_ball_query_msg(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
+                      const float *xyz, int32_t *idx0, int32_t *idx1, gp_stream_t s) {
+    if (b < 0 || n <= 0 || m < 0 || nsample0 <= 0 || nsample1 <= 0 || !new_xyz || !xyz || !idx0 || !idx1) return GP_EINVAL;
+    if ((size_t)n * 12 > 60 * 1024) return GP_EINVAL;
+    if (b == 0 || m == 0) return GP_OK;
+    dim3 grid((m + (BQ_T / 64) * BQ_CPW - 1) / ((BQ_T / 64) * BQ_CPW), b);
+    hipLaunchKernelGGL((ball_query_kernel<2, true>), grid, dim3(BQ_T), (size_t)n * 12, (hipStream_t)s, n, m, radius0, nsample0, radius1,
+                       nsample1, new_xyz, xyz, idx0, idx1);
+    return gp_launch_status();
+}
+
+int gp_gather_points(int b, int c, int n, int m, const float *points, const int32_t *idx, float *out, gp_stream_t s) {
+    if (b < 0 || c < 0 || n <= 0 || m < 0 || !points || !idx || !out) return GP_EINVAL;
+    if (b == 0 || c == 0 || m == 0) return GP_OK;
+    if (c > 65535 || b > 65535) return GP_EINVAL;
+    hipLaunchKernelGGL(gather_points_kernel, dim3((m + 255) / 256, c, b), dim3(256), 0, (hipStream_t)s, c, n, m, points, idx, out);
+    return gp_launch_status();
+}
+
+int gp_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx, float *grad_points, gp_stream_t s) {
+    if (b < 0 || c < 0 || n <= 0 || m < 0 || !grad_out || !idx || !grad_points) return GP_EINVAL;
+    if (b == 0 || c == 0 || m == 0) return GP_OK;
+    if (c > 65535 || b > 65535) return GP_EINVAL;
+    hipLaunchKernelGGL(gather_points_grad_kernel, dim3((m + 255) / 256, c, b), dim3(256), 0, (hipStream_t)s, c, n, m, grad_out, idx,
+                       grad_points);
+    return gp_launch_status();
+}
+
+int gp_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int32_t *idx, float *out, gp_stream_t s) {
+    if (b < 0 || c < 0 || n <= 0 || npoints < 0 || nsample < 0 || !points || !idx || !out) return GP_EINVAL;
+    const int q = npoints * nsample;
+    if (b == 0 || c == 0 || q == 0) return GP_OK;
+    if (c > 65535 || b > 65535) return GP_EINVAL;
+    hipLaunchKernelGGL(group_points_kernel, dim3((q + 255) / 256, c, b), dim3(256), 0, (hipStream_t)s, c, n, q, points, idx, out);
+    return gp_launch_status();
+}
+
+int gp_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int32_t *idx, float *grad_points,
+                         gp_stream_t s) {
+    if (b < 0 || c < 0 || n <= 0 || npoints < 0 || nsample < 0 || !grad_out || !idx || !grad_points) return GP_EINVAL;
+    const int q = npoints * nsample;
+    if (b == 0 || c == 0 || q == 0) return GP_OK;
+    if (c > 65535 || b > 65535) return GP_EINVAL;
+    hipLaunchKernelGGL(group_points_grad_kernel, dim3((q + 255) / 256, c, b), dim3(256), 0, (hipStream_t)s, c, n, q, grad_out, idx,
+                       grad_points);
+    return gp_launch_status();
+}
+
+int gp_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, gp_stream_t s) {
+    if (b < 0 || n < 0 || m <= 0 || !unknown || !known || !dist2 || !idx) return GP_EINVAL;
+    if (b == 0 || n == 0) return GP_OK;
+    hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 3 * 2048 * sizeof(float), (hipStream_t)s, n, m, unknown, known,
+                       dist2, idx);
+    return gp_launch_status();
+}
+
+int gp_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out,
+                         gp_stream_t s) {
+    if (b < 0 || c < 0 || m <= 0 || n < 0 || !points || !idx || !weight || !out) return GP_EINVAL;
+    if (b == 0 || c == 0 || n == 0) return GP_OK;
+    if (c > 65535 || b > 65535) return GP_EINVAL;
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3((n + 255) / 256, c, b), dim3(256), 0, (hipStream_t)s, c, m, n, points, idx, weight,
+                       out);
+    return gp_launch_status();
+}
+
+int gp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx, const float *weight,
+                              float *grad_points, gp_stream_t s) {
+    if (b < 0 || c < 0 || m <= 0 || n < 0 || !grad_out || !idx || !weight || !grad_points) return GP_EINVAL;
+    if (b == 0 || c == 0 || n == 0) return GP_OK;
+    if (c > 65535 || b > 65535) return GP_EINVAL;
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3((n + 255) / 256, c, b), dim3(256), 0, (hipStream_t)s, c, n, m, grad_out, idx,
+                       weight, grad_points);
+    return gp_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// Energy ranking and top-k pose aggregation, one wave per cloud.
+// Reference: sort_poses_by_energy (networks/reward.py:131-155: rotation and translation are ranked INDEPENDENTLY by
+// their own energy channel), sort_sRT_by_energy(..., ratio, 'average') (utils/sgpa_utils.py:897-954) ==
+// cal_average_sRT (runners/evaluation_tracking.py:60-77): 6-D -> matrix (Gram-Schmidt) -> quaternion (pytorch3d
+// matrix_to_quaternion) -> sign-align w>0 -> A = mean(q q^T) -> eigenvector of the largest eigenvalue
+// (utils/misc.py:227-249) + mean translation.  The reference does this through .cpu().numpy().tolist() index lists
+// and torch.linalg.eigh; here it is one launch (4x4 Jacobi in f64 registers).
+#include "gp_common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void rot6_to_matrix(const T *p, double R[3][3]) {
+    // get_rot_matrix('rot_matrix') (utils/misc.py:136): columns b1, b2, b3 = b1 x b2
+    double a1[3] = {(double)p[0], (double)p[1], (double)p[2]}, a2[3] = {(double)p[3], (double)p[4], (double)p[5]};
+    double n1 = sqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    n1 = n1 > 1e-12 ? n1 : 1e-12;
+    double b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    double d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    double c[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    double n2 = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    n2 = n2 > 1e-12 ? n2 : 1e-12;
+    double b2[3] = {c[0] / n2, c[1] / n2, c[2] / n2};
+    double b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+    for (int i = 0; i < 3; ++i) R[i][0] = b1[i], R[i][1] = b2[i], R[i][2] = b3[i];
+}
+
+__device__ __forceinline__ void matrix_to_quat(const double m[3][3], double q[4]) {
+    // pytorch3d v0.7.2 matrix_to_quaternion: candidate with the largest |q_i|, divisor floored at 0.1
+    double qa[4] = {1.0 + m[0][0] + m[1][1] + m[2][2], 1.0 + m[0][0] - m[1][1] - m[2][2], 1.0 - m[0][0] + m[1][1] - m[2][2],
+                    1.0 - m[0][0] - m[1][1] + m[2][2]};
+    int best = 0;
+    for (int i = 0; i < 4; ++i) qa[i] = qa[i] > 0 ? sqrt(qa[i]) : 0.0;
+    for (int i = 1; i < 4; ++i)
+        if (qa[i] > qa[best]) best = i;
+    double c[4];
+    if (best == 0) {
+        c[0] = qa[0] * qa[0], c[1] = m[2][1] - m[1][2], c[2] = m[0][2] - m[2][0], c[3] = m[1][0] - m[0][1];
+    } else if (best == 1) {
+        c[0] = m[2][1] - m[1][2], c[1] = qa[1] * qa[1], c[2] = m[1][0] + m[0][1], c[3] = m[0][2] + m[2][0];
+    } else if (best == 2) {
+        c[0] = m[0][2] - m[2][0], c[1] = m[1][0] + m[0][1], c[2] = qa[2] * qa[2], c[3] = m[1][2] + m[2][1];
+    } else {
+        c[0] = m[1][0] - m[0][1], c[1] = m[2][0] + m[0][2], c[2] = m[2][1] + m[1][2], c[3] = qa[3] * qa[3];
+    }
+    const double den = 2.0 * (qa[best] > 0.1 ? qa[best] : 0.1);
+    for (int i = 0; i < 4; ++i) q[i] = c[i] / den;
+}
+
+// eigenvector of the largest eigenvalue of a symmetric 4x4 (cyclic Jacobi)
+__device__ void top_eigvec4(double A[4][4], double v[4]) {
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-60) break;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 4; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (A[i][i] > A[best][best]) best = i;
+    for (int i = 0; i < 4; ++i) v[i] = V[i][best];
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void rank_aggregate_kernel(int k, int sel, const T *__restrict__ poses, const float *__restrict__ energy,
+                                                            T *__restrict__ sorted_poses, float *__restrict__ sorted_energy,
+                                                            int32_t *__restrict__ order, float *__restrict__ avg_pose) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *e = reinterpret_cast<float *>(smem);                   // [k][2]
+    int *ord = reinterpret_cast<int *>(e + 2 * k);                // [k][2]: candidate index at each rank
+    double *quat = reinterpret_cast<double *>(ord + 2 * k);  // [sel][4] (offset 16k bytes: 8-byte aligned)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    poses += (size_t)b * k * 9;
+    energy += (size_t)b * k * 2;
+    for (int i = tid; i < 2 * k; i += 64) e[i] = energy[i];
+    __syncthreads();
+    // stable descending rank by counting (torch.sort(descending=True); ties keep candidate order)
+    for (int i = tid; i < k; i += 64) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float ei = e[2 * i + c];
+            int r = 0;
+            for (int j = 0; j < k; ++j) {
+                const float ej = e[2 * j + c];
+                r += (ej > ei) || (ej == ei && j < i);
+            }
+            ord[2 * r + c] = i;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < k; r += 64) {
+        const int ir = ord[2 * r + 0], it = ord[2 * r + 1];
+        const size_t o = ((size_t)b * k + r);
+        if (order) {
+            order[o * 2 + 0] = ir;
+            order[o * 2 + 1] = it;
+        }
+        if (sorted_energy) {
+            sorted_energy[o * 2 + 0] = e[2 * ir + 0];
+            sorted_energy[o * 2 + 1] = e[2 * it + 1];
+        }
+        if (sorted_poses) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) sorted_poses[o * 9 + j] = poses[(size_t)ir * 9 + j];
+#pragma unroll
+            for (int j = 6; j < 9; ++j) sorted_poses[o * 9 + j] = poses[(size_t)it * 9 + j];
+        }
+    }
+    if (!avg_pose) return;
+    for (int r = tid; r < sel; r += 64) {
+        double R[3][3], q[4];
+        rot6_to_matrix<T>(poses + (size_t)ord[2 * r + 0] * 9, R);
+        matrix_to_quat(R, q);
+        const double sgn = q[0] > 0 ? 1.0 : -1.0;  // ((q_w > 0) - 0.5) * 2  (misc.py:242)
+        for (int i = 0; i < 4; ++i) quat[4 * r + i] = sgn * q[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double A[4][4] = {};
+        for (int r = 0; r < sel; ++r)
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) A[i][j] += quat[4 * r + i] * quat[4 * r + j];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) A[i][j] /= (double)sel;
+        double v[4];
+        top_eigvec4(A, v);
+        const double sgn = v[0] > 0 ? 1.0 : -1.0;
+        float *o = avg_pose + (size_t)b * 7;
+        for (int i = 0; i < 4; ++i) o[i] = (float)(sgn * v[i]);
+        double tm[3] = {0, 0, 0};
+        for (int r = 0; r < sel; ++r) {
+            const T *p = poses + (size_t)ord[2 * r + 1] * 9 + 6;
+            tm[0] += (double)p[0], tm[1] += (double)p[1], tm[2] += (double)p[2];
+        }
+        for (int i = 0; i < 3; ++i) o[4 + i] = (float)(tm[i] / (double)sel);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gp_rank_aggregate(int b, int k, int sel, int is_f64, const void *poses, const float *energy, void *sorted_poses, float *sorted_energy,
+                      int32_t *order, float *avg_pose, gp_stream_t s) {
+    if (b < 0 || k <= 0 || k > 2048 || !poses || !energy) return GP_EINVAL;
+    if (avg_pose && (sel <= 0 || sel > k)) return GP_EINVAL;
+    if (b == 0) return GP_OK;
+    const size_t lds = (size_t)k * 16 + 16 + (size_t)(avg_pose ? sel : 0) * 32;
+    if (is_f64)
+        hipLaunchKernelGGL(rank_aggregate_kernel<double>, dim3(b), dim3(64), lds, (hipStream_t)s, k, sel, (const double *)poses, energy,
+                           (double *)sorted_poses, sorted_energy, order, avg_pose);
+    else
+        hipLaunchKernelGGL(rank_aggregate_kernel<float>, dim3(b), dim3(64), lds, (hipStream_t)s, k, sel, (const float *)poses, energy,
+                           (float *)sorted_poses, sorted_energy, order, avg_pose);
+    return gp_launch_status();
+}
+
+}  // extern "C"

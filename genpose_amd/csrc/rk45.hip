@@ -1,0 +1,473 @@
+// Probability-flow ODE sampler on the device: Dormand-Prince 5(4) with scipy's step controller, f64 state,
+// f32 score network - the semantics of cond_ode_sampler (networks/gf_algorithms/samplers.py:163-227) driving
+// scipy.integrate.solve_ivp(method='RK45', rtol=atol=1e-5) (scipy/_ivp/rk.py, common.py).
+//
+// The reference keeps the f64 state on the HOST and crosses PCIe twice per function evaluation
+// (samplers.py:187,191).  Here state, stage derivatives, t, h and the accept/reject decision all live in HBM:
+//   rk45_init_a / _b / _c : f0, Hairer initial step (two evaluations), first stage times
+//   per attempt           : time_embed(6 stage times) -> 6 fused stage kernels (stage update + score) -> rk45_decide
+//   rk45_finish           : denoise step (samplers.py:209-218), normalize_rotation, + centre
+// The error norm is the reference's batch-global RMS over all R*9 components: per-tile partial sums, reduced in
+// a fixed order by the single-workgroup decide kernel (deterministic).
+#include "score_trunk.h"
+
+namespace {
+
+using namespace gp_trunk;
+
+// Dormand-Prince tableau (Dormand & Prince 1980; the constants scipy's RK45 uses)
+__constant__ double DP_C[7] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+__constant__ double DP_A[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},  // B (stage 6 = y_new)
+};
+__constant__ double DP_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+
+constexpr double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10.0;
+constexpr double SIG_MIN = 0.01, SIG_RATIO = 50.0 / 0.01;
+
+// Device-resident solver state (one per sampler instance).
+struct Rk45State {
+    double t, h_abs, t_bound, direction, rtol, atol;
+    double h;              // signed step of the attempt in flight
+    double d0, d1, h0;     // initial-step scratch
+    double err_norm;       // of the last attempt
+    int status;            // 0 running, 1 finished, -1 step size too small
+    int last_accepted;     // previous attempt accepted -> stage 1 commits y_new/K6 first
+    int step_rejected;     // a rejection happened since the last accepted step
+    int n_attempts, n_accepted, nfev;
+    int traj_cap;
+    float stage_t[8];      // f32 times fed to the network (stages 1..6 at [1..6]; [0] = misc evaluations)
+    float stage_sigma[8];  // f32 sigma(t) the network divides by (scorenet.py:205,217)
+    double stage_g2[8];    // f64 g(t)^2 of the PF-ODE right-hand side (sde.py:20-24 on a 0-dim f64 tensor)
+    double log_t[512], log_h[512], log_err[512];  // per attempt (diagnostics / parity tests)
+    int log_acc[512];
+};
+
+__device__ __forceinline__ void set_stage(Rk45State *st, int slot, double t) {
+    const float tf = (float)t;  // torch.ones(R,1) * t  -> f32 (samplers.py:192)
+    st->stage_t[slot] = tf;
+    st->stage_sigma[slot] = 0.01f * powf(5000.0f, tf);
+    const double sg = SIG_MIN * pow(SIG_RATIO, t);
+    const double g = sg * sqrt(2.0 * (log(50.0) - log(0.01)));
+    st->stage_g2[slot] = g * g;
+}
+
+struct OdeArgs {
+    int nrows, kcand, nblocks;
+    const float *cvec, *tvec;  // tvec [8][768] (slot-indexed like stage_t)
+    const float *centre;
+    Rk45State *st;
+    double *y, *ynew, *K;      // y, ynew [R*9]; K [7][R*9]
+    double *partials;          // [3][nblocks]
+    double *traj;              // [traj_cap][R*9] accepted states (raw, un-normalised) or null
+    float *x32;                // [R*9] scratch
+};
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    double s = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __syncthreads();
+    return s;
+}
+
+// Fused stage kernel.  STAGE 1..6: Runge-Kutta stage;  STAGE 0: f0 = fun(t0, y0) (+ d0,d1 partials);
+// STAGE 7: f1 = fun(t0 + h0*dir, y0 + h0*dir*f0) (+ d2 partial).
+template <int P, int STAGE>
+__global__ __launch_bounds__(256, 2) void rk45_stage_kernel(OdeArgs a, gp_scorenet net) {
+    using L = TrunkLds<P>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double sh[4];
+    const int row0 = blockIdx.x * P, tid = threadIdx.x;
+    Rk45State *st = a.st;
+    if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
+    const size_t n = (size_t)a.nrows * 9;
+    const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
+    const double h = st->h;
+    if (tid < P) {
+        const bool live = row0 + tid < a.nrows;
+        const int r = live ? row0 + tid : a.nrows - 1;
+        double ys[9];
+        if (STAGE == 1 && st->last_accepted) {
+            // commit the previous accepted step for this tile's rows (row-local: no other block touches them)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const size_t e = (size_t)r * 9 + j;
+                const double v = a.ynew[e];
+                if (live) {
+                    a.y[e] = v;
+                    a.K[e] = a.K[6 * n + e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const size_t e = (size_t)r * 9 + j;
+            double yv = (STAGE == 1 && st->last_accepted) ? a.ynew[e] : a.y[e];
+            if (STAGE >= 1 && STAGE <= 6) {
+                double dy = 0.0;
+#pragma unroll
+                for (int q = 0; q < STAGE; ++q) {
+                    const double kq = (q == 0 && STAGE == 1 && st->last_accepted) ? a.K[6 * n + e] : a.K[(size_t)q * n + e];
+                    dy += kq * DP_A[STAGE][q];
+                }
+                yv = yv + dy * h;  // rk.py: dy = dot(K[:s].T, a[:s]) * h ; y + dy   (stage 6: y + h * dot(K[:-1].T, B))
+                if (STAGE == 6 && live) a.ynew[e] = yv;
+            } else if (STAGE == 7) {
+                yv = yv + st->h0 * st->direction * a.K[e];  // common.py: y1 = y0 + h0 * direction * f0
+            }
+            ys[j] = yv;
+        }
+        float *xr = lds + tid * L::LD0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) xr[j] = (float)ys[j];  // torch.tensor(x, dtype=float32) (samplers.py:191)
+#pragma unroll
+        for (int j = 9; j < 16; ++j) xr[j] = 0.f;
+    }
+    __syncthreads();
+    trunk_ftheta<P>(lds, net, a.cvec, a.tvec + (size_t)slot * HEADS, row0, a.nrows, a.kcand);
+    const float sigma = st->stage_sigma[slot];
+    const double g2 = st->stage_g2[slot];
+    const float *F = lds + L::OFF_H1;
+    double *Kout = a.K + (size_t)(STAGE == 7 ? 1 : (STAGE == 0 ? 0 : (STAGE == 6 ? 6 : STAGE))) * n;
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int e = tid; e < P * POSE; e += 256) {
+        const int r = e / POSE, j = e - r * POSE;
+        if (row0 + r >= a.nrows) continue;
+        const size_t ge = (size_t)(row0 + r) * 9 + j;
+        const float score = F[r * L::LDH + j] / (sigma + 1e-7f);
+        const double kv = 0.0 - (0.5 * g2) * (double)score;  // drift - 0.5 * g^2 * score (samplers.py:198)
+        Kout[ge] = kv;
+        if (STAGE == 0) {
+            const double yv = a.y[ge];
+            const double sc = st->atol + fabs(yv) * st->rtol;
+            acc0 += (yv / sc) * (yv / sc);
+            acc1 += (kv / sc) * (kv / sc);
+        } else if (STAGE == 7) {
+            const double sc = st->atol + fabs(a.y[ge]) * st->rtol;
+            const double d = (kv - a.K[ge]) / sc;
+            acc0 += d * d;
+        } else if (STAGE == 6) {
+            double er = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) er += a.K[(size_t)q * n + ge] * DP_E[q];
+            er += kv * DP_E[6];
+            er *= h;  // rk.py: dot(K.T, E) * h
+            const double yo = a.y[ge], yn = a.ynew[ge];
+            const double sc = st->atol + fmax(fabs(yo), fabs(yn)) * st->rtol;
+            acc0 += (er / sc) * (er / sc);
+        }
+    }
+    if (STAGE == 0 || STAGE == 6 || STAGE == 7) {
+        const double s0 = block_sum(acc0, sh);
+        if (tid == 0) a.partials[blockIdx.x] = s0;
+        if (STAGE == 0) {
+            const double s1 = block_sum(acc1, sh);
+            if (tid == 0) a.partials[a.nblocks + blockIdx.x] = s1;
+        }
+    }
+}
+
+__device__ __forceinline__ double sum_partials(const double *p, int nb, double *sh) {
+    double s = 0.0;
+    for (int q = threadIdx.x; q < nb; q += 256) s += p[q];
+    return block_sum(s, sh);
+}
+
+// Prepare the next attempt: clamp the step to t_bound and publish the six stage times (rk.py:119-142).
+__device__ void begin_attempt(Rk45State *st) {
+    const double t = st->t, dir = st->direction;
+    const double min_step = 10.0 * fabs(nextafter(t, dir * INFINITY) - t);
+    double h_abs = st->h_abs;
+    if (h_abs < min_step) {
+        if (st->step_rejected) {  // inside the rejection loop scipy fails here (rk.py:132-133)
+            st->status = -1;
+            return;
+        }
+        h_abs = min_step;  // start of _step_impl: clamp (rk.py:123-124)
+    }
+    double h = h_abs * dir, t_new = t + h;
+    if (dir * (t_new - st->t_bound) > 0) t_new = st->t_bound;
+    h = t_new - t;
+    st->h = h;
+    st->h_abs = fabs(h);
+    for (int s = 1; s <= 6; ++s) set_stage(st, s, t + DP_C[s] * h);
+}
+
+// mode 0: after f0 (d0, d1 -> h0, stage slot 0 = t0 + h0*dir);  mode 1: after f1 (d2 -> h_abs, first attempt);
+// mode 2: after an attempt (error norm -> accept / reject -> next attempt)
+__global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
+    __shared__ double sh[4];
+    Rk45State *st = a.st;
+    const double nn = (double)a.nrows * 9.0;
+    if (mode == 0) {
+        const double s0 = sum_partials(a.partials, a.nblocks, sh);
+        const double s1 = sum_partials(a.partials + a.nblocks, a.nblocks, sh);
+        if (threadIdx.x == 0) {
+            const double d0 = sqrt(s0) / sqrt(nn), d1 = sqrt(s1) / sqrt(nn);  // norm(x) = |x|_2 / sqrt(size)
+            const double interval = fabs(st->t_bound - st->t);
+            double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+            h0 = fmin(h0, interval);
+            st->d0 = d0, st->d1 = d1, st->h0 = h0;
+            set_stage(st, 0, st->t + h0 * st->direction);
+            st->nfev = 1;
+        }
+    } else if (mode == 1) {
+        const double s0 = sum_partials(a.partials, a.nblocks, sh);
+        if (threadIdx.x == 0) {
+            const double d2 = (sqrt(s0) / sqrt(nn)) / st->h0;
+            const double d1 = st->d1;
+            double h1;
+            if (d1 <= 1e-15 && d2 <= 1e-15)
+                h1 = fmax(1e-6, st->h0 * 1e-3);
+            else
+                h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+            const double interval = fabs(st->t_bound - st->t);
+            st->h_abs = fmin(fmin(100.0 * st->h0, h1), interval);
+            st->nfev = 2;
+            st->last_accepted = 0;
+            st->step_rejected = 0;
+            begin_attempt(st);
+        }
+    } else {
+        if (st->status != 0) return;
+        const double s0 = sum_partials(a.partials, a.nblocks, sh);
+        if (threadIdx.x == 0) {
+            const double err = sqrt(s0) / sqrt(nn);
+            const int ia = st->n_attempts;
+            if (ia < 512) {
+                st->log_t[ia] = st->t;
+                st->log_h[ia] = st->h;
+                st->log_err[ia] = err;
+                st->log_acc[ia] = err < 1.0;
+            }
+            st->n_attempts = ia + 1;
+            st->nfev += 6;
+            st->err_norm = err;
+            double h_abs = st->h_abs;
+            if (err < 1.0) {
+                double factor = (err == 0.0) ? MAX_FACTOR : fmin(MAX_FACTOR, SAFETY * pow(err, -0.2));
+                if (st->step_rejected) factor = fmin(1.0, factor);
+                h_abs *= factor;
+                st->t = st->t + st->h;  // t_new (already clamped to t_bound in begin_attempt)
+                st->last_accepted = 1;
+                st->step_rejected = 0;
+                st->n_accepted += 1;
+                if (st->direction * (st->t - st->t_bound) >= 0) st->status = 1;
+            } else {
+                h_abs *= fmax(MIN_FACTOR, SAFETY * pow(err, -0.2));
+                st->last_accepted = 0;
+                st->step_rejected = 1;
+            }
+            st->h_abs = h_abs;
+            if (st->status == 0) begin_attempt(st);
+        }
+    }
+}
+
+// Record the accepted state (raw) into the trajectory; runs after decide (multi-block, elementwise).
+__global__ void rk45_record_kernel(OdeArgs a) {
+    const Rk45State *st = a.st;
+    if (!a.traj || !st->last_accepted) return;
+    const int slot = st->n_accepted;  // slot 0 holds y0
+    if (slot >= st->traj_cap) return;
+    const size_t n = (size_t)a.nrows * 9;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        a.traj[(size_t)slot * n + e] = a.ynew[e];
+}
+
+// Denoise (samplers.py:209-218) + normalize_rotation + centre (:224-226); also post-processes the trajectory.
+template <int P>
+__global__ __launch_bounds__(256, 2) void rk45_finish_kernel(OdeArgs a, gp_scorenet net, double denoise_scale, int do_denoise, double *x_out) {
+    using L = TrunkLds<P>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int row0 = blockIdx.x * P, tid = threadIdx.x;
+    const Rk45State *st = a.st;
+    const double *yfin = st->last_accepted ? a.ynew : a.y;
+    if (tid < P) {
+        const int r = row0 + tid < a.nrows ? row0 + tid : a.nrows - 1;
+        float *xr = lds + tid * L::LD0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) xr[j] = (float)yfin[(size_t)r * 9 + j];  // x.float() (:214)
+#pragma unroll
+        for (int j = 9; j < 16; ++j) xr[j] = 0.f;
+    }
+    __syncthreads();
+    trunk_ftheta<P>(lds, net, a.cvec, a.tvec, row0, a.nrows, a.kcand);  // slot 0 = eps
+    const float sigma = st->stage_sigma[0];
+    const float *F = lds + L::OFF_H1;
+    if (tid < P && row0 + tid < a.nrows) {
+        const int r = row0 + tid;
+        double xv[9];
+        // vec_eps is an f32 [R,1] tensor: g = sigma * sqrt(2 ln 5000) evaluated in f32 (sde.py:20-24)
+        const float g = sigma * 4.1272735595703125f;  // (float)sqrt(2*(ln 50 - ln 0.01))
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float grad = F[tid * L::LDH + j] / (sigma + 1e-7f);
+            const float drift = 0.f - (g * g) * grad;                    // R-SDE sign as written (:216)
+            const float dx = drift * (float)denoise_scale;               // f32 tensor * python float stays f32
+            xv[j] = yfin[(size_t)r * 9 + j] + (do_denoise ? (double)dx : 0.0);
+        }
+        normalize_rot6<double>(xv);
+        const float *cen = a.centre + (size_t)(r / a.kcand) * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xv[6 + j] += (double)cen[j];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) x_out[(size_t)r * 9 + j] = xv[j];
+    }
+}
+
+// normalize_rotation + centre on every recorded state (samplers.py:220-224)
+__global__ void rk45_traj_post_kernel(int nrows, int kcand, int nstates, const float *__restrict__ centre, double *__restrict__ traj) {
+    const size_t total = (size_t)nstates * nrows;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i % nrows);
+        double *v = traj + i * 9;
+        double xv[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) xv[j] = v[j];
+        normalize_rot6<double>(xv);
+        const float *cen = centre + (size_t)(r / kcand) * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xv[6 + j] += (double)cen[j];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v[j] = xv[j];
+    }
+}
+
+__global__ void rk45_reset_kernel(Rk45State *st, double t0, double t_bound, double rtol, double atol, int traj_cap, double eps_time) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->t = t0, st->t_bound = t_bound, st->direction = t_bound >= t0 ? 1.0 : -1.0;
+    st->rtol = rtol, st->atol = atol;
+    st->h = 0, st->h_abs = 0, st->d0 = st->d1 = st->h0 = 0, st->err_norm = 0;
+    st->status = 0, st->last_accepted = 0, st->step_rejected = 0;
+    st->n_attempts = 0, st->n_accepted = 0, st->nfev = 0, st->traj_cap = traj_cap;
+    // the very first evaluation gets a python-float t: sde_coeff(torch.tensor(t)) is f32 there;
+    // the f64 formula differs by <= 1e-7 relative - documented deviation.
+    for (int i = 0; i < 8; ++i) st->stage_t[i] = 0.f, st->stage_sigma[i] = 1.f, st->stage_g2[i] = 0.0;
+    set_stage(st, 0, t0);
+    (void)eps_time;
+}
+
+__global__ void rk45_set_slot0_kernel(Rk45State *st, double t) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) set_stage(st, 0, t);
+}
+
+template <typename K>
+int set_lds_attr(K kern, size_t lds) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? GP_OK
+                                                                                                                                            : GP_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gp_rk45_state_bytes(void) { return (int64_t)sizeof(Rk45State); }
+
+/* Field offsets for host-side inspection: fills out[0..15] with byte offsets of
+ * t, h_abs, status, n_attempts, n_accepted, nfev, err_norm, log_t, log_h, log_err, log_acc, stage_t, last_accepted */
+int gp_rk45_state_layout(int64_t *out, int n) {
+    if (!out || n < 13) return GP_EINVAL;
+    out[0] = offsetof(Rk45State, t);
+    out[1] = offsetof(Rk45State, h_abs);
+    out[2] = offsetof(Rk45State, status);
+    out[3] = offsetof(Rk45State, n_attempts);
+    out[4] = offsetof(Rk45State, n_accepted);
+    out[5] = offsetof(Rk45State, nfev);
+    out[6] = offsetof(Rk45State, err_norm);
+    out[7] = offsetof(Rk45State, log_t);
+    out[8] = offsetof(Rk45State, log_h);
+    out[9] = offsetof(Rk45State, log_err);
+    out[10] = offsetof(Rk45State, log_acc);
+    out[11] = offsetof(Rk45State, stage_t);
+    out[12] = offsetof(Rk45State, last_accepted);
+    return GP_OK;
+}
+
+static int ode_args(OdeArgs *a, int nclouds, int k, const float *cvec, const float *tvec, const float *centre, void *state, double *y,
+                    double *ynew, double *K, double *partials, double *traj, float *x32) {
+    if (nclouds <= 0 || k <= 0 || !cvec || !tvec || !centre || !state || !y || !ynew || !K || !partials) return GP_EINVAL;
+    a->nrows = nclouds * k, a->kcand = k, a->nblocks = (a->nrows + SCORE_P - 1) / SCORE_P;
+    a->cvec = cvec, a->tvec = tvec, a->centre = centre, a->st = (Rk45State *)state;
+    a->y = y, a->ynew = ynew, a->K = K, a->partials = partials, a->traj = traj, a->x32 = x32;
+    return GP_OK;
+}
+
+/* Phase driver.  Every phase is a fixed launch sequence on stream s (graph-capturable):
+ *   phase 0: reset state (t0 -> t_bound), y must hold y0; copies y0 into traj slot 0 when traj != NULL
+ *   phase 1: f0 + d0/d1 -> h0          [needs tvec slot 0 = time_embed(stage_t[0]) BEFORE it: see gp_rk45_stage_times]
+ *   phase 2: f1 + d2 -> h_abs, first attempt's stage times
+ *   phase 3: one attempt: 6 stage kernels + decide + record
+ *   phase 4: set slot 0 to `eps_t` (denoise evaluation time)
+ *   phase 5: finish: denoise + normalise + centre -> x_out [R,9] f64; post-process nstates trajectory states
+ * Between phases the caller runs gp_time_embed(8, net, stage_times_dev, tvec) where stage_times_dev points at
+ * Rk45State.stage_t (offset from gp_rk45_state_layout). */
+int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state,
+                  double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap, double t0, double t_bound, double rtol,
+                  double atol, double denoise_scale, int do_denoise, int nstates, double *x_out, gp_stream_t s) {
+    OdeArgs a;
+    int rc = ode_args(&a, nclouds, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
+    if (rc != GP_OK || !net) return GP_EINVAL;
+    hipStream_t st = (hipStream_t)s;
+    const size_t lds = trunk_lds_bytes<SCORE_P>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (set_lds_attr(rk45_stage_kernel<SCORE_P, 0>, lds) || set_lds_attr(rk45_stage_kernel<SCORE_P, 1>, lds) ||
+            set_lds_attr(rk45_stage_kernel<SCORE_P, 2>, lds) || set_lds_attr(rk45_stage_kernel<SCORE_P, 3>, lds) ||
+            set_lds_attr(rk45_stage_kernel<SCORE_P, 4>, lds) || set_lds_attr(rk45_stage_kernel<SCORE_P, 5>, lds) ||
+            set_lds_attr(rk45_stage_kernel<SCORE_P, 6>, lds) || set_lds_attr(rk45_stage_kernel<SCORE_P, 7>, lds) ||
+            set_lds_attr(rk45_finish_kernel<SCORE_P>, lds))
+            return GP_ELAUNCH;
+        attr_done = true;
+    }
+    const dim3 grid(a.nblocks), blk(256);
+    const size_t n = (size_t)a.nrows * 9;
+    switch (phase) {
+        case 0:
+            hipLaunchKernelGGL(rk45_reset_kernel, dim3(1), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
+            if (traj && hipMemcpyAsync(traj, y, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return GP_ELAUNCH;
+            break;
+        case 1:
+            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 0>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 0);
+            break;
+        case 2:
+            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 7>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 1);
+            break;
+        case 3:
+            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 1>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 2>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 3>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 4>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 5>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 6>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 2);
+            if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64), blk, 0, st, a);
+            break;
+        case 4:
+            hipLaunchKernelGGL(rk45_set_slot0_kernel, dim3(1), dim3(64), 0, st, a.st, t0);
+            break;
+        case 5:
+            if (!x_out) return GP_EINVAL;
+            hipLaunchKernelGGL((rk45_finish_kernel<SCORE_P>), grid, blk, lds, st, a, *net, denoise_scale, do_denoise, x_out);
+            if (traj && nstates > 0)
+                hipLaunchKernelGGL(rk45_traj_post_kernel, dim3(128), blk, 0, st, a.nrows, a.kcand, nstates, centre, traj);
+            break;
+        default:
+            return GP_EINVAL;
+    }
+    return gp_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// Fused set-abstraction scale: neighbourhood gather -> 3-layer shared MLP (BN folded, ReLU) on fp32 MFMA ->
+// max over the neighbourhood.  Replaces QueryAndGroup/GroupAll + SharedMLP + F.max_pool2d of the reference
+// (pointnet2_utils.py:232-291, pytorch_utils.py:5-32, pointnet2_modules.py:37-52) and never materialises the
+// grouped [B, C+3, np, ns] tensor (12 MB/cloud in the reference).
+//
+// One 256-thread workgroup owns P consecutive (centre, sample) rows of one cloud:
+//   gather rows into LDS  [P][K0pad+8]   (feature columns first, then dx,dy,dz, zero pad)
+//   layer 1: LDS A -> LDS B,  layer 2: LDS B -> LDS A,  layer 3: LDS A -> registers -> max -> global.
+// Weights stream from L2 straight into MFMA A-operand registers (host-packed fragment order, gp_common.h).
+#include "gp_common.h"
+
+namespace {
+
+struct SAArgs {
+    int n, np, ns, cin, c1, c2, c3;
+    const float *xyz, *feats_in, *new_xyz;
+    const int32_t *idx;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    float *out;
+    int cout_total, cout_off, groupall;
+};
+
+template <int P, int WN, int NTB>
+__global__ __launch_bounds__(256) void sa_mlp_kernel(SAArgs a) {
+    constexpr int WP = 4 / WN;
+    constexpr int PT = P / 16 / WP;
+    static_assert(PT >= 1 && PT * 16 * WP == P, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, row0 = blockIdx.x * P;
+    const int K0 = a.cin + 3, K0p = gp_round16(K0);
+    const int c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
+    const int lda = (K0p > c2p ? K0p : c2p) + GP_LD_PAD, ldb = c1p + GP_LD_PAD;
+    float *A = lds, *Bf = lds + P * lda;
+    const int nrows = a.groupall ? a.n : a.np * a.ns;
+
+    const float *xyz = a.xyz + (size_t)b * a.n * 3;
+    const float *fin = a.feats_in ? a.feats_in + (size_t)b * a.n * a.cin : nullptr;
+    // ---- gather: xyz part (+ zero pad) : one thread per row
+    for (int r = tid; r < P; r += 256) {
+        int g = row0 + r;
+        if (g >= nrows) g = nrows - 1;
+        int j;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (a.groupall) {
+            j = g;
+        } else {
+            const int c = g / a.ns;
+            j = a.idx[((size_t)b * a.np) * a.ns + g];
+            const float *cp = a.new_xyz + ((size_t)b * a.np + c) * 3;
+            cx = cp[0], cy = cp[1], cz = cp[2];
+        }
+        float *row = A + r * lda + a.cin;
+        row[0] = xyz[j * 3 + 0] - cx;  // grouped_xyz -= new_xyz (pointnet2_utils.py:253)
+        row[1] = xyz[j * 3 + 1] - cy;
+        row[2] = xyz[j * 3 + 2] - cz;
+        for (int k = K0; k < K0p; ++k) A[r * lda + k] = 0.f;
+    }
+    // ---- gather: feature part, float4 granules, consecutive threads -> consecutive granules of a row
+    if (fin) {
+        const int q4 = a.cin >> 2;  // cin is a multiple of 4 (96 / 256 / 512)
+        for (int e = tid; e < P * q4; e += 256) {
+            const int r = e / q4, q = e - r * q4;
+            int g = row0 + r;
+            if (g >= nrows) g = nrows - 1;
+            const int j = a.groupall ? g : a.idx[((size_t)b * a.np) * a.ns + g];
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(fin + (size_t)j * a.cin + 4 * q);
+            *reinterpret_cast<f32x4 *>(A + r * lda + 4 * q) = v;
+        }
+    }
+    __syncthreads();
+    dense_to_lds<NTB, PT, WN, true>(A, lda, a.w1, a.b1, K0, a.c1, Bf, ldb);
+    __syncthreads();
+    dense_to_lds<NTB, PT, WN, true>(Bf, ldb, a.w2, a.b2, a.c1, a.c2, A, lda);
+    __syncthreads();
+    // ---- layer 3 + max over the neighbourhood, straight from the accumulators
+    {
+        const int wn = wave % WN, wp = wave / WN;
+        const int KG = c2p / 16, NC = gp_round16(a.c3) / 16;
+        const int pc0 = wp * PT;
+        const int G = a.groupall ? PT : a.ns / 16;  // p-chunks per centre
+        float *outb = a.out + (size_t)b * a.np * a.cout_total + a.cout_off;
+        for (int ncb = wn; ncb < NC; ncb += WN * NTB) {
+            int nc[NTB];
+#pragma unroll
+            for (int i = 0; i < NTB; ++i) nc[i] = (ncb + i * WN < NC) ? ncb + i * WN : -1;
+            f32x4 acc[NTB][PT];
+            mfma_tile<NTB, PT>(A, lda, pc0, a.w3, KG, nc, acc);
+#pragma unroll
+            for (int i = 0; i < NTB; ++i) {
+                if (nc[i] < 0) continue;
+                const int ch = nc[i] * 16 + 4 * (lane >> 4);
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b3 + ch);
+                f32x4 m = {0.f, 0.f, 0.f, 0.f};  // ReLU output is >= 0
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                    f32x4 v = acc[i][p] + bv;
+                    m.x = fmaxf(m.x, v.x);
+                    m.y = fmaxf(m.y, v.y);
+                    m.z = fmaxf(m.z, v.z);
+                    m.w = fmaxf(m.w, v.w);
+                    if ((p + 1) % G == 0) {
+                        m.x = row16_max(m.x);
+                        m.y = row16_max(m.y);
+                        m.z = row16_max(m.z);
+                        m.w = row16_max(m.w);
+                        if ((lane & 15) == 0 && ch < a.c3) {
+                            if (a.groupall) {
+                                unsigned int *o = reinterpret_cast<unsigned int *>(outb + ch);
+                                atomicMax(o + 0, __float_as_uint(m.x));
+                                atomicMax(o + 1, __float_as_uint(m.y));
+                                atomicMax(o + 2, __float_as_uint(m.z));
+                                atomicMax(o + 3, __float_as_uint(m.w));
+                            } else {
+                                const int centre = (row0 + (pc0 + p + 1 - G) * 16) / a.ns;
+                                if (centre < a.np) *reinterpret_cast<f32x4 *>(outb + (size_t)centre * a.cout_total + ch) = m;
+                            }
+                        }
+                        m = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int P, int WN, int NTB>
+int launch(const SAArgs &a, int b, hipStream_t st) {
+    const int K0p = gp_round16(a.cin + 3), c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
+    const int lda = (K0p > c2p ? K0p : c2p) + GP_LD_PAD, ldb = c1p + GP_LD_PAD;
+    const size_t lds = (size_t)P * (lda + ldb) * sizeof(float);
+    if (lds > 160 * 1024) return GP_EINVAL;
+    auto kern = sa_mlp_kernel<P, WN, NTB>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GP_ELAUNCH;
+    }
+    const int nrows = a.groupall ? a.n : a.np * a.ns;
+    hipLaunchKernelGGL(kern, dim3((nrows + P - 1) / P, b), dim3(256), lds, st, a);
+    return gp_launch_status();
+}
+
+size_t lds_bytes(int P, const SAArgs &a) {
+    const int K0p = gp_round16(a.cin + 3), c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
+    return (size_t)P * ((K0p > c2p ? K0p : c2p) + c1p + 2 * GP_LD_PAD) * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3, const float *xyz, const float *feats_in,
+                  const float *new_xyz, const int32_t *idx, const float *wpack1, const float *bias1, const float *wpack2,
+                  const float *bias2, const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off,
+                  gp_stream_t s) {
+    if (b < 0 || n <= 0 || np <= 0 || ns <= 0 || cin < 0 || c1 <= 0 || c2 <= 0 || c3 <= 0) return GP_EINVAL;
+    if (!xyz || !wpack1 || !bias1 || !wpack2 || !bias2 || !wpack3 || !bias3 || !out) return GP_EINVAL;
+    if ((cin & 3) || (cin > 0 && !feats_in) || (cout_total & 3) || (cout_off & 3) || (c3 & 3)) return GP_EINVAL;
+    if (cout_off + c3 > cout_total) return GP_EINVAL;
+    const bool groupall = (idx == nullptr);
+    if (groupall && (np != 1 || new_xyz != nullptr || ns != n)) return GP_EINVAL;
+    if (!groupall && (!new_xyz || (ns % 16) != 0)) return GP_EINVAL;
+    if (b == 0) return GP_OK;
+    SAArgs a{n, np, ns, cin, c1, c2, c3, xyz, feats_in, new_xyz, idx, wpack1, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off,
+             groupall ? 1 : 0};
+    hipStream_t st = (hipStream_t)s;
+    if (groupall) return launch<32, 4, 4>(a, b, st);
+    const int wide = (c1 > 64 || c2 > 64 || c3 > 64);
+    if (!wide) {
+        // narrow layers (SA level 0): waves tile the POINT dimension so none idles on a 16-channel layer
+        if (ns == 16) return launch<64, 1, 2>(a, b, st);
+        if (ns == 32) return launch<64, 2, 2>(a, b, st);
+        if (ns == 64) return launch<64, 4, 2>(a, b, st);
+        return GP_EINVAL;
+    }
+    if (ns > 64) return GP_EINVAL;
+    if (lds_bytes(64, a) <= 150 * 1024) return launch<64, 4, 4>(a, b, st);
+    if (ns <= 32) return launch<32, 4, 4>(a, b, st);
+    return GP_EINVAL;
+}
+
+int64_t gp_pack_weight_size(int n_out, int k_in) { return (int64_t)(gp_round16(n_out) / 16) * (gp_round16(k_in) / 16) * 256; }
+
+int gp_pack_weight(int n_out, int k_in, const float *W, int ldw, float *packed) {
+    if (n_out <= 0 || k_in <= 0 || !W || !packed || ldw < k_in) return GP_EINVAL;
+    const int NC = gp_round16(n_out) / 16, KG = gp_round16(k_in) / 16;
+    for (int nc = 0; nc < NC; ++nc)
+        for (int kg = 0; kg < KG; ++kg)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int n = nc * 16 + (lane & 15), k = kg * 16 + 4 * (lane >> 4) + jj;
+                    packed[(((size_t)nc * KG + kg) * 64 + lane) * 4 + jj] = (n < n_out && k < k_in) ? W[(size_t)n * ldw + k] : 0.f;
+                }
+    return GP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+"""PointNet++(MSG) encoder on the HIP kernels - drop-in for `Pointnet2ClsMSG(0)` (networks/pts_encoder/pointnet2.py:166-211).
+
+forward(pts [B,N,3] f32 on the GPU) -> [B,1024].  Launch sequence per call (all on torch's current stream):
+  1 x gp_fps_chain      FPS + gather for every level (one workgroup per cloud)
+  L x gp_ball_query_msg both radii of a level in one pass
+  2L x gp_sa_mlp_max    gather -> 3-layer MLP on fp32 MFMA -> max-pool, per scale
+  2 x gp_sa_mlp_max     GroupAll level (integer atomic max into a zeroed buffer)
+Intermediate features stay point-major [B, n, C]; the reference's grouped [B,C+3,np,ns] tensors never exist.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ptr, stream_ptr
+from .weights import EncoderWeights
+
+
+class Pointnet2EncoderHIP:
+    def __init__(self, state_dict, device="cuda", params="light", prefix="pts_encoder."):
+        self.device = torch.device(device)
+        self.w = EncoderWeights(state_dict, self.device, params, prefix)
+        self.cfg = self.w.cfg
+        self.out_dim = self.w.out_dim
+        self._ws = {}
+
+    # ------------------------------------------------------------------ workspace (cached per batch/size)
+    def _workspace(self, B, N):
+        key = (B, N)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev = self.device
+        ws = {"fps_idx": [], "new_xyz": [], "bq": [], "feat": []}
+        n = N
+        for k, npnt in enumerate(self.cfg["npoints"]):
+            cout = sum(s.couts[-1] for s in self.w.levels[k])
+            if npnt is None:
+                ws["feat"].append(torch.zeros(B, 1, cout, device=dev))
+                break
+            ws["fps_idx"].append(torch.empty(B, npnt, dtype=torch.int32, device=dev))
+            ws["new_xyz"].append(torch.empty(B, npnt, 3, device=dev))
+            ws["bq"].append([torch.empty(B, npnt, ns, dtype=torch.int32, device=dev) for ns in self.cfg["nsamples"][k]])
+            ws["feat"].append(torch.empty(B, npnt, cout, device=dev))
+            n = npnt
+        self._ws[key] = ws
+        return ws
+
+    def forward(self, pts, return_intermediates=False):
+        _lib.check_device()
+        if not pts.is_cuda or pts.dtype != torch.float32:
+            raise RuntimeError("pts must be a float32 CUDA tensor")
+        xyz0 = pts[..., 0:3].contiguous()
+        B, N, _ = xyz0.shape
+        ws = self._workspace(B, N)
+        st = stream_ptr()
+        cfg = self.cfg
+        group_levels = [k for k, npnt in enumerate(cfg["npoints"]) if npnt is not None]
+        # ---- furthest point sampling + gather for every level
+        if len(group_levels) <= 3 and N <= 1024:
+            m = (ctypes.c_int * 3)(*([cfg["npoints"][k] for k in group_levels] + [0] * (3 - len(group_levels))))
+            pi = [ptr(ws["fps_idx"][l]) if l < len(group_levels) else None for l in range(3)]
+            px = [ptr(ws["new_xyz"][l]) if l < len(group_levels) else None for l in range(3)]
+            _lib.call("gp_fps_chain", B, N, len(group_levels), m, ptr(xyz0), pi[0], px[0], pi[1], px[1], pi[2], px[2], st)
+        else:
+            cur = xyz0
+            for l, k in enumerate(group_levels):
+                npnt = cfg["npoints"][k]
+                temp = torch.full((B, cur.shape[1]), 1e10, device=self.device)
+                _lib.call("gp_furthest_point_sampling", B, cur.shape[1], npnt, ptr(cur), ptr(temp), ptr(ws["fps_idx"][l]), st)
+                torch.gather(cur, 1, ws["fps_idx"][l].long().unsqueeze(-1).expand(B, npnt, 3), out=ws["new_xyz"][l])
+                cur = ws["new_xyz"][l]
+        # ---- set abstraction levels
+        xyz, feats, n, cin = xyz0, None, N, 0
+        for k, npnt in enumerate(cfg["npoints"]):
+            scales = self.w.levels[k]
+            out = ws["feat"][k]
+            cout_total = out.shape[-1]
+            if npnt is None:
+                out.zero_()
+                off = 0
+                for sc in scales:
+                    (w1, b1), (w2, b2), (w3, b3) = sc.layers
+                    _lib.call("gp_sa_mlp_max", B, n, 1, n, cin, sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(feats), None, None,
+                              ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out), cout_total, off, st)
+                    off += sc.couts[2]
+                feats, n, cin = out, 1, cout_total
+                break
+            new_xyz = ws["new_xyz"][k]
+            radii, nss = cfg["radii"][k], cfg["nsamples"][k]
+            if len(scales) == 2:
+                _lib.call("gp_ball_query_msg", B, n, npnt, float(radii[0]), nss[0], float(radii[1]), nss[1], ptr(new_xyz), ptr(xyz),
+                          ptr(ws["bq"][k][0]), ptr(ws["bq"][k][1]), st)
+            else:
+                for i in range(len(scales)):
+                    ws["bq"][k][i].zero_()
+                    _lib.call("gp_ball_query", B, n, npnt, float(radii[i]), nss[i], ptr(new_xyz), ptr(xyz), ptr(ws["bq"][k][i]), st)
+            off = 0
+            for i, sc in enumerate(scales):
+                (w1, b1), (w2, b2), (w3, b3) = sc.layers
+                _lib.call("gp_sa_mlp_max", B, n, npnt, nss[i], cin, sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(feats),
+                          ptr(new_xyz), ptr(ws["bq"][k][i]), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out), cout_total,
+                          off, st)
+                off += sc.couts[2]
+            xyz, feats, n, cin = new_xyz, out, npnt, cout_total
+        res = feats.reshape(B, -1).clone()
+        if return_intermediates:
+            return res, ws
+        return res
+
+    __call__ = forward

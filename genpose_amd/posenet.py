@@ -1,0 +1,124 @@
+"""GFObjectPose on the HIP kernels - same constructor arguments and string-dispatched forward as the reference's
+networks/posenet.py:18-179, inference modes only:
+
+    net(data, mode='pts_feature')                      -> [B,1024]          (posenet.py:71-91)
+    net(data, mode='score' | 'energy')                 -> [R,9] | [R,2]     (posenet.py:159-164)
+    net(data, mode='pc_sample' | 'ode_sample', init_x=, T0=) -> (in_process [R,S,9], res [R,9])  (posenet.py:94-130)
+
+`data` is the reference's dict of device tensors ('pts', 'pts_feat', 'sampled_pose', 't', 'pts_center').
+Extra (not in the reference): data may carry '_repeat' = K, meaning 'pts_feat'/'pts_center' hold one row per CLOUD
+and every cloud owns K consecutive pose rows - this is how PoseNet.pred_func avoids the K-fold repeat of the inputs
+(posenet_agent.py:426-434 repeats even the raw clouds: 315 MB at B=256).
+"""
+import torch
+
+from .encoder import Pointnet2EncoderHIP
+from .samplers import ODESampler, PCSampler
+from .scorenet import ScoreNetHIP
+from .sde import SIGMA_MAX, SIGMA_MIN
+
+
+class GFObjectPose:
+    def __init__(self, cfg, prior_fn, marginal_prob_fn, sde_fn, sampling_eps, T):
+        self.cfg = cfg
+        self.device = torch.device(cfg.device)
+        self.prior_fn, self.marginal_prob_fn, self.sde_fn = prior_fn, marginal_prob_fn, sde_fn
+        self.sampling_eps, self.T = sampling_eps, T
+        if cfg.pts_encoder != "pointnet2":
+            raise NotImplementedError(f"pts_encoder '{cfg.pts_encoder}': only the default PointNet++ encoder is on the MI355X hot path")
+        if getattr(cfg, "regression_head", "Rx_Ry_and_T") != "Rx_Ry_and_T" or getattr(cfg, "pose_mode", "rot_matrix") != "rot_matrix":
+            raise NotImplementedError("only regression_head='Rx_Ry_and_T' with pose_mode='rot_matrix' is implemented")
+        if cfg.posenet_mode not in ("score", "energy"):
+            raise NotImplementedError(cfg.posenet_mode)
+        if cfg.posenet_mode == "energy":
+            for k, v in (("energy_mode", "IP"), ("s_theta_mode", "score"), ("norm_energy", "identical")):
+                if getattr(cfg, k, v) != v:
+                    raise NotImplementedError(f"{k}='{getattr(cfg, k)}' (only the shipped default '{v}')")
+        self.pts_encoder = None
+        self.pose_score_net = None
+        self._samplers = {}
+        self.training = False
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+        params = getattr(self.cfg, "pointnet2_params", "light")
+        self.pts_encoder = Pointnet2EncoderHIP(sd, self.device, params)
+        self.pose_score_net = ScoreNetHIP(sd, self.device)
+        self._samplers = {}
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, device):
+        return self
+
+    def _need_weights(self):
+        if self.pose_score_net is None:
+            raise RuntimeError("GFObjectPose has no weights: call load_state_dict()/PoseNet.load_ckpt() first")
+
+    # ------------------------------------------------------------------ pieces
+    def extract_pts_feature(self, data):
+        self._need_weights()
+        return self.pts_encoder(data["pts"])
+
+    def _rows(self, data):
+        """-> (cvec [B,768], K, centre [B,3] or None)"""
+        K = int(data.get("_repeat", 1))
+        cvec = self.pose_score_net.cloud_embed(data["pts_feat"].float())
+        return cvec, K
+
+    def sample(self, data, sampler, init_x=None, T0=None, noise=None, return_process=True):
+        self._need_weights()
+        cvec, K = self._rows(data)
+        B = cvec.shape[0]
+        R = B * K
+        centre = data["pts_center"].float()
+        if sampler == "pc":
+            n = self.cfg.sampling_steps
+            if n is None:
+                raise ValueError("the PC sampler needs cfg.sampling_steps")
+            x0 = self.prior_fn((R, 9)).to(self.device) if init_x is None else init_x.float()
+            key = ("pc", B, K, n, return_process)
+            smp = self._samplers.get(key)
+            if smp is None:
+                smp = self._samplers[key] = PCSampler(self.pose_score_net, B, K, n, self.device, record_traj=return_process)
+            z1, z2 = noise if noise is not None else (None, None)
+            xs, res = smp.run(cvec, centre, x0, z1, z2)
+            return (xs.clone() if xs is not None else None), res.clone()
+        if sampler == "ode":
+            T0 = self.T if T0 is None else T0
+            pr = self.prior_fn((R, 9), T=T0).to(self.device)
+            x0 = pr if init_x is None else init_x.float() + pr
+            key = ("ode", B, K)
+            smp = self._samplers.get(key)
+            if smp is None:
+                smp = self._samplers[key] = ODESampler(self.pose_score_net, B, K, self.device)
+            return smp.run(cvec, centre, x0, T0, num_steps=self.cfg.sampling_steps, eps=self.sampling_eps, return_process=return_process)
+        raise NotImplementedError(sampler)
+
+    # ------------------------------------------------------------------ string dispatch (posenet.py:150-179)
+    def forward(self, data, mode="score", init_x=None, T0=None):
+        if mode == "pts_feature":
+            return self.extract_pts_feature(data)
+        if mode in ("score", "energy"):
+            self._need_weights()
+            if (mode == "energy") != (self.cfg.posenet_mode == "energy"):
+                raise NotImplementedError("score-from-energy (autograd) and energy-from-score paths are outside the inference hot path")
+            K = int(data.get("_repeat", 1))
+            if K == 1:
+                return self.pose_score_net.forward_rows(data["pts_feat"], data["sampled_pose"], data["t"], mode)
+            cvec = self.pose_score_net.cloud_embed(data["pts_feat"].float())
+            t0 = data["t"].reshape(-1)[:1].float().contiguous()
+            tvec = self.pose_score_net.time_embed(t0)
+            sigma = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t0).contiguous()
+            return self.pose_score_net.evaluate(cvec, K, data["sampled_pose"].float().contiguous(), tvec[0], sigma, mode)
+        if mode == "pc_sample":
+            return self.sample(data, "pc", init_x=init_x)
+        if mode == "ode_sample":
+            return self.sample(data, "ode", init_x=init_x, T0=T0)
+        raise NotImplementedError(mode)
+
+    __call__ = forward

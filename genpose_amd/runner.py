@@ -1,0 +1,116 @@
+"""Runner loops over the agent: the batch / frame loops of runners/evaluation_single.py:309-489 and
+runners/evaluation_tracking.py:262-337 restated around the HIP agent.
+
+Inputs  : lists / arrays of [1024,3] float32 clouds (camera frame, metres, NOT centred); for tracking also per-frame
+          `model_name`s and an initial sRT per object.
+Outputs : multi_hypothesis_pred_RTs [n,K,4,4] (float64, as the reference's numpy RTs), energy [n,K,2], aggregated
+          sRT [n,4,4].
+Detection pre-processing (depth+mask -> cloud) and mAP evaluation are the "next" rows of SURVEY §8f.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import reward, rotation
+
+
+def make_batch_sample(pts):
+    """The dict the agents consume (evaluation_single.py:394-403): `pts` stays un-centred, `pts_center` is the mean."""
+    pts = pts.float()
+    centre = torch.mean(pts[:, :, :3], dim=1)
+    return {"pts": pts, "zero_mean_pts": pts - centre.unsqueeze(1), "pts_center": centre}
+
+
+class SingleFrameRunner:
+    """inference_pose + inference_energy (evaluation_single.py:356-489) without the pickle round trip in between."""
+
+    def __init__(self, score_agent, energy_agent=None, repeat_num=50, T0=0.55, batch_size=256, ratio=0.6):
+        self.score_agent, self.energy_agent = score_agent, energy_agent
+        self.repeat_num, self.T0, self.batch_size, self.ratio = repeat_num, T0, batch_size, ratio
+
+    def infer(self, clouds, device="cuda"):
+        """clouds: array-like [n,1024,3].  Returns dict of numpy arrays (+ 'pred_pose' [n,K,9])."""
+        clouds = torch.as_tensor(np.asarray(clouds), dtype=torch.float32)
+        n = clouds.shape[0]
+        out = {"pred_pose": [], "multi_hypothesis_pred_RTs": [], "energy": [], "sorted_RTs": [], "average_sRT": []}
+        for s in range(0, n, self.batch_size):  # evaluation_single.py:380-382 batch slicing
+            sample = make_batch_sample(clouds[s:s + self.batch_size].to(device))
+            pred = self.score_agent.pred_func(data=sample, repeat_num=self.repeat_num, save_path=None, T0=self.T0)
+            out["pred_pose"].append(pred.cpu().numpy())
+            out["multi_hypothesis_pred_RTs"].append(rotation.pose9_to_RT(pred).cpu().numpy())
+            if self.energy_agent is not None:
+                energy = self.energy_agent.get_energy(data=sample, pose_samples=pred, T=1e-5)  # evaluation_single.py:339-343
+                r = reward.rank_aggregate(pred, energy, ratio=self.ratio)
+                out["energy"].append(energy.cpu().numpy())
+                out["sorted_RTs"].append(rotation.pose9_to_RT(r["sorted_poses"]).cpu().numpy())
+                out["average_sRT"].append(rotation.quat_trans_to_RT(r["avg_pose"].double()).cpu().numpy())
+        return {k: np.concatenate(v, axis=0) for k, v in out.items() if v}
+
+
+# ------------------------------------------------------------------ tracking
+def _unit(q):
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def add_noise_to_RT(RT, r=5.0, t=0.03, draws=None):
+    """Initial-pose jitter of the tracking runner (utils/tracking_utils.py:37-101, 'normal' mode): rotate by
+    |N(0,1)|*r degrees about a random axis orthogonal (in quaternion space) to the current rotation and shift by
+    N(0,1)*t metres along a random direction.  `draws` (tests): the four standard-normal tensors in call order
+    (theta [B], quaternion [B,4], shift norm [B], direction [B,3])."""
+    B = RT.shape[0]
+    if draws is None:
+        draws = [torch.randn(B), torch.randn(B, 4), torch.randn(B), torch.randn(B, 3)]
+    d_theta, d_q, d_norm, d_dir = [d.to(RT) for d in draws]
+    Rm = RT[:, :3, :3]
+    theta = (d_theta.abs() * (r / 180 * math.pi)).unsqueeze(-1)
+    tr = torch.clamp(1 + Rm[:, 0, 0] + Rm[:, 1, 1] + Rm[:, 2, 2], min=0.0)
+    rr = torch.sqrt(tr)
+    s = 1.0 / (2 * rr + 1e-7)
+    q = _unit(torch.stack((0.5 * rr, (Rm[:, 2, 1] - Rm[:, 1, 2]) * s, (Rm[:, 0, 2] - Rm[:, 2, 0]) * s, (Rm[:, 1, 0] - Rm[:, 0, 1]) * s), dim=-1))
+    nq = _unit(d_q)
+    q_orth = _unit(nq - q * torch.sum(q * nq, dim=-1, keepdim=True))
+    jq = q * torch.cos(theta / 2) + q_orth * torch.sin(theta / 2)
+    w, x, y, z = torch.unbind(jq, dim=-1)
+    new_R = torch.stack((1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w,
+                         2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w,
+                         2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y), dim=-1).reshape(B, 3, 3)
+    out = RT.clone()
+    out[:, :3, :3] = new_R
+    direction = d_dir / torch.clamp(d_dir.norm(dim=-1, keepdim=True), min=1e-9)
+    out[:, :3, 3] = RT[:, :3, 3] + direction * (d_norm * t).unsqueeze(-1)
+    return out
+
+
+class TrackingRunner:
+    """Frame-by-frame tracking with warm-started candidates (main_tracking, evaluation_tracking.py:262-337):
+    every instance of a frame forms one batch; the initial pose of an object is the previous frame's aggregated
+    sRT for the same `model_name`, else a jittered ground-truth pose; the ODE sampler starts at T0 = 0.15 from
+    init_x + prior(T0) (samplers.py:180)."""
+
+    def __init__(self, score_agent, energy_agent, repeat_num=50, T0=0.15, ratio=0.6):
+        self.score_agent, self.energy_agent = score_agent, energy_agent
+        self.repeat_num, self.T0, self.ratio = repeat_num, T0, ratio
+        self.buffer = {"model_name": [], "pred_sRT": None}
+
+    def reset(self):
+        self.buffer = {"model_name": [], "pred_sRT": None}
+
+    def step(self, pts, model_names, gt_RT, noise_draws=None):
+        """pts [n,1024,3] device tensor; gt_RT [n,4,4] (used only for objects not seen in the previous frame)."""
+        sample = make_batch_sample(pts)
+        dev = sample["pts"].device
+        init_sRT = add_noise_to_RT(gt_RT.float().cpu(), draws=noise_draws).to(dev)  # drawn every frame (:302)
+        for i, name in enumerate(model_names):
+            if name in self.buffer["model_name"]:
+                init_sRT[i] = self.buffer["pred_sRT"][self.buffer["model_name"].index(name)]
+        init_x = init_sRT[:, :3, [0, 1, 3]].permute(0, 2, 1).reshape(init_sRT.shape[0], -1)  # [R[:,0], R[:,1], t]
+        init_x[:, -3:] -= sample["pts_center"]
+        pred = self.score_agent.pred_func(data=sample, repeat_num=self.repeat_num, save_path=None, init_x=init_x, T0=self.T0)
+        energy = self.energy_agent.get_energy(data=sample, pose_samples=pred, T=1e-5)
+        sel = max(1, int(self.ratio * self.repeat_num))
+        r = reward.rank_aggregate(pred, energy, selected_num=sel)
+        average_sRT = rotation.quat_trans_to_RT(r["avg_pose"])
+        self.buffer = {"model_name": list(model_names), "pred_sRT": average_sRT}
+        return {"init_x": init_x, "pred_pose": pred, "energy": energy, "sorted_RTs": rotation.pose9_to_RT(r["sorted_poses"]),
+                "average_sRT": average_sRT}

@@ -1,0 +1,210 @@
+"""Samplers on the HIP kernels: cond_pc_sampler / cond_ode_sampler of networks/gf_algorithms/samplers.py:102-227
+(pose_mode 'rot_matrix', VE SDE).  Host code only builds schedule tables, owns buffers and replays hipGraphs;
+every per-step operation runs in csrc/scorenet.hip / csrc/rk45.hip.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr, stream_ptr
+from .sde import EPS, SIGMA_MAX, SIGMA_MIN, ve_sde
+
+
+def pc_schedule(num_steps, eps=EPS):
+    """Host schedule table of the PC sampler: [num_steps,4] = sigma(t_i), g(t_i), step_size, sqrt(step_size),
+    evaluated with the reference's own f32 tensor expressions (samplers.py:118-119,145; sde.py:15-24)."""
+    time_steps = torch.linspace(1.0, eps, num_steps)
+    step_size = time_steps[0] - time_steps[1]
+    bt = time_steps.reshape(-1, 1)
+    sigma = SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** bt
+    _, g = ve_sde(bt)
+    sched = torch.cat([sigma, g, step_size.expand(num_steps, 1), torch.sqrt(step_size).expand(num_steps, 1)], dim=1)
+    return time_steps, sched.float().contiguous()
+
+
+class PCSampler:
+    """Predictor-corrector sampler state for a fixed (B, K, num_steps): buffers + optional hipGraph of the whole loop."""
+
+    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False):
+        self.net, self.B, self.K, self.n = net, B, K, num_steps
+        self.dev = torch.device(device)
+        R = B * K
+        self.R = R
+        self.tile = _lib.lib().gp_score_tile_rows()
+        self.nblocks = (R + self.tile - 1) // self.tile
+        ts, sched = pc_schedule(num_steps)
+        self.sched = sched.to(self.dev)
+        self.tvec_all = net.time_embed(ts.to(self.dev))
+        f = lambda *s: torch.empty(*s, device=self.dev)
+        self.x, self.mean_x, self.score = f(R, 9), f(R, 9), f(R, 9)
+        self.partials = torch.zeros(num_steps, self.nblocks, device=self.dev)
+        self.z1, self.z2 = f(num_steps, R, 9), f(num_steps, R, 9)
+        self.cvec, self.centre = f(B, 768), f(B, 3)
+        self.traj = f(num_steps, R, 9) if record_traj else None
+        self.use_graph = use_graph
+        self.graph = None
+
+    def _launch_all(self):
+        st = stream_ptr()
+        w = self.net.w.ref()
+        for i in range(self.n + 1):
+            _lib.call("gp_pc_step", self.B, self.K, i, self.n, w, ptr(self.cvec), ptr(self.tvec_all), ptr(self.sched), ptr(self.z1),
+                      ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
+                      ptr(self.traj), st)
+
+    def run(self, cvec, centre, init_x, z_langevin=None, z_predictor=None):
+        """cvec [B,768], centre [B,3], init_x [R,9]; noise [n,R,9] (drawn on the device generator if None).
+        Returns (xs [R,n,9] or None, mean_x [R,9]) float32, like cond_pc_sampler."""
+        self.cvec.copy_(cvec)
+        self.centre.copy_(centre)
+        self.x.copy_(init_x)
+        if z_langevin is None:
+            self.z1.normal_()
+            self.z2.normal_()
+        else:
+            self.z1.copy_(z_langevin)
+            self.z2.copy_(z_predictor)
+        if not self.use_graph:
+            self._launch_all()
+        else:
+            if self.graph is None:
+                # warm-up launch outside capture (sets kernel attributes), then capture the whole T-step loop once
+                x0 = self.x.clone()
+                self._launch_all()
+                torch.cuda.synchronize()
+                self.x.copy_(x0)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._launch_all()
+            self.graph.replay()
+        xs = self.traj.permute(1, 0, 2) if self.traj is not None else None
+        return xs, self.mean_x
+
+
+# ---------------------------------------------------------------------------------------------- PF-ODE (RK45)
+_STATE_FIELDS = ("t", "h_abs", "status", "n_attempts", "n_accepted", "nfev", "err_norm", "log_t", "log_h", "log_err", "log_acc",
+                 "stage_t", "last_accepted")
+
+
+def _state_layout():
+    import ctypes
+    arr = (ctypes.c_int64 * 16)()
+    _lib.call("gp_rk45_state_layout", arr, 16)
+    return {n: int(arr[i]) for i, n in enumerate(_STATE_FIELDS)}, int(_lib.lib().gp_rk45_state_bytes())
+
+
+class ODESampler:
+    """cond_ode_sampler (samplers.py:163-227) with the whole Dormand-Prince loop resident on the GPU.
+
+    One *attempt* (stage-time embedding + 6 fused stage kernels + controller) is captured as a hipGraph and replayed;
+    the host only polls the device-side `status` word every `poll` attempts (the number of attempts is data dependent:
+    scipy's adaptive controller, rtol = atol = 1e-5, batch-global RMS error norm)."""
+
+    TRAJ_CAP = 192
+
+    def __init__(self, net, B, K, device, use_graph=True, poll=8):
+        self.net, self.B, self.K = net, B, K
+        self.dev = torch.device(device)
+        R = self.R = B * K
+        self.tile = _lib.lib().gp_score_tile_rows()
+        self.nblocks = (R + self.tile - 1) // self.tile
+        self.layout, nbytes = _state_layout()
+        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
+        d = lambda *s: torch.zeros(*s, dtype=torch.float64, device=self.dev)
+        self.y, self.ynew, self.Kbuf = d(R * 9), d(R * 9), d(7, R * 9)
+        self.partials = d(3, self.nblocks)
+        self.x_out = d(R, 9)
+        self.tvec = torch.zeros(8, 768, device=self.dev)
+        self.cvec = torch.empty(B, 768, device=self.dev)
+        self.centre = torch.empty(B, 3, device=self.dev)
+        self.traj = None
+        self.use_graph, self.poll = use_graph, poll
+        self.graph = None
+        self.graph_traj = None
+        self.last_stats = {}
+
+    def _phase(self, phase, traj=None, t0=0.0, t_bound=0.0, rtol=1e-5, atol=1e-5, dscale=0.0, do_denoise=1, nstates=0):
+        import ctypes
+        cd = ctypes.c_double
+        _lib.call("gp_rk45_phase", phase, self.B, self.K, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec), ptr(self.centre),
+                  ptr(self.state), ptr(self.y), ptr(self.ynew), ptr(self.Kbuf), ptr(self.partials), ptr(traj),
+                  0 if traj is None else traj.shape[0], cd(t0), cd(t_bound), cd(rtol), cd(atol), cd(dscale), do_denoise, nstates,
+                  ptr(self.x_out), stream_ptr())
+
+    def _embed(self):
+        import ctypes
+        stage_t = ctypes.c_void_p(self.state.data_ptr() + self.layout["stage_t"])
+        _lib.call("gp_time_embed", 8, self.net.w.ref(), stage_t, ptr(self.tvec), stream_ptr())
+
+    def _attempt(self, traj):
+        self._embed()
+        self._phase(3, traj)
+
+    def _read_state(self):
+        raw = self.state.cpu().numpy()
+        L = self.layout
+        g = lambda name, dt, n=1: np.frombuffer(raw.tobytes(), dtype=dt, count=n, offset=L[name])
+        st = {k: g(k, np.int32)[0] for k in ("status", "n_attempts", "n_accepted", "nfev")}
+        st.update({k: g(k, np.float64)[0] for k in ("t", "h_abs", "err_norm")})
+        na = min(int(st["n_attempts"]), 512)
+        st["log_t"], st["log_h"], st["log_err"] = (g(k, np.float64, 512)[:na].copy() for k in ("log_t", "log_h", "log_err"))
+        st["log_acc"] = g("log_acc", np.int32, 512)[:na].copy()
+        return st
+
+    def run(self, cvec, centre, init_x, T0, num_steps=None, eps=EPS, rtol=1e-5, atol=1e-5, denoise=True, return_process=False,
+            max_attempts=4096):
+        """Returns (xs [R,S,9] f64 or None, x [R,9] f64).  With num_steps=None the in-process samples are the accepted
+        states (like solve_ivp without t_eval)."""
+        if return_process and num_steps is not None:
+            raise NotImplementedError("in-process samples at t_eval points need RK45 dense output (not on the hot path yet); "
+                                      "use sampling_steps=None or return_process=False")
+        self.cvec.copy_(cvec)
+        self.centre.copy_(centre)
+        self.y.copy_(init_x.reshape(-1).double())  # init_x f32 -> f64 state (solve_ivp casts y0 to float64)
+        traj = None
+        if return_process:
+            if self.traj is None:
+                self.traj = torch.zeros(self.TRAJ_CAP, self.R * 9, dtype=torch.float64, device=self.dev)
+            traj = self.traj
+        self._phase(0, traj, t0=T0, t_bound=eps, rtol=rtol, atol=atol)
+        self._embed()
+        self._phase(1, traj)
+        self._embed()
+        self._phase(2, traj)
+        n_done = 0
+        while True:
+            if self.use_graph:
+                gname = "graph_traj" if traj is not None else "graph"
+                if getattr(self, gname) is None:
+                    self._attempt(traj)  # warm-up outside capture
+                    n_done += 1
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for _ in range(self.poll):
+                            self._attempt(traj)
+                    setattr(self, gname, g)
+                getattr(self, gname).replay()
+            else:
+                for _ in range(self.poll):
+                    self._attempt(traj)
+            n_done += self.poll
+            st = self._read_state()
+            if st["status"] != 0:
+                break
+            if n_done >= max_attempts:
+                raise RuntimeError("ODE sampler: attempt budget exhausted")
+        if st["status"] < 0:
+            raise RuntimeError("ODE sampler: required step size is less than spacing between numbers (scipy TOO_SMALL_STEP)")
+        self._phase(4, traj, t0=eps)
+        self._embed()
+        nstates = int(st["n_accepted"]) + 1 if traj is not None else 0
+        if traj is not None and nstates > self.TRAJ_CAP:
+            raise RuntimeError(f"ODE sampler: {nstates} accepted states exceed the trajectory capacity {self.TRAJ_CAP}")
+        dscale = (1 - eps) / (1000 if num_steps is None else num_steps)
+        self._phase(5, traj, dscale=dscale, do_denoise=1 if denoise else 0, nstates=nstates)
+        st["nfev"] = int(st["nfev"]) + (1 if denoise else 0)
+        self.last_stats = st
+        xs = None
+        if traj is not None:
+            xs = traj[:nstates].reshape(nstates, self.R, 9).permute(1, 0, 2).clone()
+        return xs, self.x_out.clone()

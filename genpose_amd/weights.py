@@ -1,0 +1,128 @@
+"""State-dict -> device weight blocks for the HIP kernels.
+
+Accepts exactly the reference's `model_state_dict` key schema (posenet_agent.py:143-173):
+  pts_encoder.SA_modules.{k}.mlps.{i}.layer{l}.conv.weight [Cout,Cin,1,1], ....bn.bn.{weight,bias,running_mean,running_var}
+  pose_score_net.{pose_encoder.{0,2}, t_encoder.0.W, t_encoder.1, fusion_tail_{rot_x,rot_y,trans}.{0,2}}.{weight,bias}
+so a real `ckpt_genpose.pth` drops in.  Host-side work here is layout only: BatchNorm (eval) folding into the
+1x1 conv, input-channel permutation [dx,dy,dz,feat] -> [feat,dx,dy,dz], and the MFMA
+fragment packing of gp_pack_weight (include/genpose_hip.h).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+# networks/pts_encoder/pointnet2.py:24-78 (input_channels = 0, use_xyz=True)
+ENCODER_CFGS = {
+    "light": dict(npoints=[512, 256, 128, None], radii=[[0.02, 0.04], [0.04, 0.08], [0.08, 0.16], [None, None]],
+                  nsamples=[[16, 32], [16, 32], [16, 32], [None, None]],
+                  mlps=[[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]], [[128, 196, 256], [128, 196, 256]],
+                        [[256, 256, 512], [256, 384, 512]]]),
+    "dense": dict(npoints=[512, 256, 128, None], radii=[[0.02, 0.04], [0.04, 0.08], [0.08, 0.16], [None, None]],
+                  nsamples=[[32, 64], [16, 32], [8, 16], [None, None]],
+                  mlps=[[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]], [[128, 196, 256], [128, 196, 256]],
+                        [[256, 256, 512], [256, 384, 512]]]),
+    "lighter": dict(npoints=[512, 256, 128, 64, None], radii=[[0.01], [0.02], [0.04], [0.08], [None]],
+                    nsamples=[[64], [32], [16], [8], [None]],
+                    mlps=[[[32, 32, 64]], [[64, 64, 128]], [[128, 196, 256]], [[256, 256, 512]], [[512, 512, 1024]]]),
+}
+BN_EPS = 1e-5
+
+
+def _round16(v):
+    return (v + 15) // 16 * 16
+
+
+def pack_weight(W):
+    """W [n_out, k_in] (CPU f32) -> packed MFMA A-operand stream (CPU f32), see gp_common.h."""
+    W = W.detach().to(torch.float32).contiguous().cpu()
+    n, k = W.shape
+    size = _lib.lib().gp_pack_weight_size(n, k)
+    out = torch.empty(size, dtype=torch.float32)
+    _lib.call("gp_pack_weight", n, k, ctypes.c_void_p(W.data_ptr()), k, ctypes.c_void_p(out.data_ptr()))
+    return out
+
+
+def pad_bias(b):
+    b = b.detach().to(torch.float32).cpu()
+    out = torch.zeros(_round16(b.numel()), dtype=torch.float32)
+    out[: b.numel()] = b
+    return out
+
+
+class SAScale:
+    """One (level, scale) of the encoder: three folded layers."""
+
+    def __init__(self, sd, prefix, cin_feat, device):
+        self.cin = cin_feat
+        self.layers = []
+        self.couts = []
+        l = 0
+        while f"{prefix}layer{l}.conv.weight" in sd:
+            p = f"{prefix}layer{l}."
+            W = sd[p + "conv.weight"].detach().double().cpu().reshape(sd[p + "conv.weight"].shape[0], -1)
+            gamma, beta = sd[p + "bn.bn.weight"].double().cpu(), sd[p + "bn.bn.bias"].double().cpu()
+            mean, var = sd[p + "bn.bn.running_mean"].double().cpu(), sd[p + "bn.bn.running_var"].double().cpu()
+            scale = gamma / torch.sqrt(var + BN_EPS)
+            Wf = W * scale[:, None]
+            bf = beta - mean * scale
+            if l == 0:
+                if Wf.shape[1] != cin_feat + 3:
+                    raise ValueError(f"{p}conv.weight has {Wf.shape[1]} input channels, expected {cin_feat + 3}")
+                Wf = torch.cat([Wf[:, 3:], Wf[:, :3]], dim=1)  # [dx,dy,dz,feat] -> [feat,dx,dy,dz]
+            self.layers.append((pack_weight(Wf.float()).to(device), pad_bias(bf.float()).to(device)))
+            self.couts.append(Wf.shape[0])
+            l += 1
+        if l != 3:
+            raise ValueError(f"{prefix}: the fused SA kernel expects 3-layer shared MLPs, found {l}")
+
+
+class EncoderWeights:
+    def __init__(self, sd, device, params="light", prefix="pts_encoder."):
+        if params not in ENCODER_CFGS:
+            raise NotImplementedError(params)
+        self.cfg = ENCODER_CFGS[params]
+        self.levels = []
+        cin = 0
+        for k, level in enumerate(self.cfg["mlps"]):
+            scales = [SAScale(sd, f"{prefix}SA_modules.{k}.mlps.{i}.", cin, device) for i in range(len(level))]
+            for sc, spec in zip(scales, level):
+                if sc.couts != list(spec):
+                    raise ValueError(f"SA level {k}: checkpoint layer widths {sc.couts} != config {spec}")
+            self.levels.append(scales)
+            cin = sum(s.couts[-1] for s in scales)
+        self.out_dim = cin
+
+
+class ScoreNetWeights:
+    """Device block behind `struct gp_scorenet` (score and energy nets share the layout, posenet.py:58-67)."""
+
+    def __init__(self, sd, device, prefix="pose_score_net."):
+        g = lambda k: sd[prefix + k].detach().to(torch.float32).cpu()
+        heads = ("rot_x", "rot_y", "trans")
+        W1 = torch.cat([g(f"fusion_tail_{h}.0.weight") for h in heads], dim=0)  # [768, 1408] = [pts 1024 | t 128 | pose 256]
+        if W1.shape != (768, 1408):
+            raise ValueError(f"unexpected fusion_tail first-layer shape {tuple(W1.shape)} (need Rx_Ry_and_T heads, 1024-d pts feature)")
+        b1 = torch.cat([g(f"fusion_tail_{h}.0.bias") for h in heads], dim=0)
+        W2 = torch.cat([g(f"fusion_tail_{h}.2.weight") for h in heads], dim=0)  # [9, 256]
+        b2 = torch.cat([g(f"fusion_tail_{h}.2.bias") for h in heads], dim=0)
+        t = {}
+        t["w_pose0"] = pack_weight(g("pose_encoder.0.weight"))
+        t["b_pose0"] = pad_bias(g("pose_encoder.0.bias"))
+        t["w_pose2"] = pack_weight(g("pose_encoder.2.weight"))
+        t["b_pose2"] = pad_bias(g("pose_encoder.2.bias"))
+        t["w_headx"] = pack_weight(W1[:, 1152:1408].contiguous())
+        t["w_out"] = W2.contiguous()
+        t["b_out"] = torch.cat([b2, torch.zeros(7)])
+        t["fourier_w"] = g("t_encoder.0.W")
+        t["w_t1"] = g("t_encoder.1.weight").t().contiguous()  # [in][out]
+        t["b_t1"] = g("t_encoder.1.bias")
+        t["w_headt"] = W1[:, 1024:1152].t().contiguous()  # [128][768]
+        t["w_headp"] = pack_weight(W1[:, :1024].contiguous())
+        t["b_head"] = b1.contiguous()
+        self.tensors = {k: v.to(device) for k, v in t.items()}
+        self.struct = _lib.GpScoreNet(**{k: v.data_ptr() for k, v in self.tensors.items()})
+
+    def ref(self):
+        return ctypes.byref(self.struct)

@@ -1,0 +1,187 @@
+/*
+ * genpose_hip.h - C ABI of libgenpose_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary for GenPose's inference hot path.  Every entry point
+ *   - takes raw DEVICE pointers, plain ints/floats and a hipStream_t passed as void* (0 = null stream),
+ *   - is stateless, allocation-free, never synchronises and never reads results back on the host
+ *     (safe to capture in a hipGraph),
+ *   - returns 0 on success or a negative GP_E* code (never exit()s, unlike the reference launchers,
+ *     e.g. ball_query_gpu.cu:62-66).
+ * Caller owns every buffer, outputs included (same convention as the reference's pybind wrappers,
+ * pointnet2_utils.py:26-27,56,95-96,129,173,219).
+ *
+ * Section A replaces, one for one, the nine pybind functions of the reference's CUDA extension
+ * `pointnet2_cuda` (networks/pts_encoder/pointnet2_utils/pointnet2/src/pointnet2_api.cpp:10-24).
+ * Sections B-D are the fused MI355X-native entry points that replace the Python/ATen glue above them
+ * (pointnet2_modules.py:19-56, scorenet.py:178-222, samplers.py:102-227, reward.py:131-155,
+ * sgpa_utils.py:897-954).
+ */
+#ifndef GENPOSE_HIP_H
+#define GENPOSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GP_OK 0
+#define GP_EINVAL (-1)   /* bad size / null pointer / unsupported shape */
+#define GP_ELAUNCH (-2)  /* hipGetLastError() != hipSuccess after a launch */
+#define GP_EARCH (-3)    /* device is not gfx950 */
+
+typedef void *gp_stream_t; /* hipStream_t */
+
+/* Library / device identification: returns ABI version; writes gcnArchName of the current device. */
+int gp_version(void);
+int gp_device_arch(char *buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------------
+ * A. pointnet2_cuda operator API (reference: pointnet2_api.cpp:10-24)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* furthest_point_sampling_wrapper (sampling.cpp:40-51, sampling_gpu.cu:86-253).
+ * xyz [b,n,3] f32; temp [b,n] f32 in/out (caller fills 1e10, pointnet2_utils.py:27; must be >= 0);
+ * idx [b,m] i32 out.  idx[:,0] = 0; ties resolved exactly as the reference's shared-memory tree does. */
+int gp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, gp_stream_t s);
+
+/* gather_points_wrapper (sampling.cpp:13-23, sampling_gpu.cu:8-44): points [b,c,n], idx [b,m] -> out [b,c,m]. */
+int gp_gather_points(int b, int c, int n, int m, const float *points, const int32_t *idx, float *out, gp_stream_t s);
+/* gather_points_grad_wrapper (sampling_gpu.cu:46-83): grad_out [b,c,m], idx [b,m] -> grad_points [b,c,n] (+=, atomic). */
+int gp_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx, float *grad_points, gp_stream_t s);
+
+/* ball_query_wrapper (ball_query.cpp:16-27, ball_query_gpu.cu:9-67).
+ * new_xyz [b,m,3], xyz [b,n,3] -> idx [b,m,nsample] i32.  First `nsample` points in index order with
+ * d2 < radius^2 (strict, radius^2 in f32); the first hit pre-fills every slot; rows with no hit are
+ * left untouched (caller pre-zeroes idx, pointnet2_utils.py:219). */
+int gp_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx, gp_stream_t s);
+
+/* group_points_wrapper (group_points.cpp:26-37, group_points_gpu.cu:47-86): points [b,c,n], idx [b,np,ns] -> out [b,c,np,ns]. */
+int gp_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int32_t *idx, float *out, gp_stream_t s);
+/* group_points_grad_wrapper (group_points_gpu.cu:8-45): grad_out [b,c,np,ns] -> grad_points [b,c,n] (+=, atomic). */
+int gp_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int32_t *idx, float *grad_points, gp_stream_t s);
+
+/* three_nn_wrapper (interpolate.cpp, interpolate_gpu.cu:9-74): unknown [b,n,3], known [b,m,3] -> dist2 [b,n,3] f32, idx [b,n,3] i32. */
+int gp_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, gp_stream_t s);
+/* three_interpolate_wrapper (interpolate_gpu.cu:77-117): points [b,c,m], idx/weight [b,n,3] -> out [b,c,n]. */
+int gp_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out, gp_stream_t s);
+/* three_interpolate_grad_wrapper (interpolate_gpu.cu:120-160): grad_out [b,c,n] -> grad_points [b,c,m] (+=, atomic). */
+int gp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx, const float *weight, float *grad_points, gp_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * B. Fused PointNet++(MSG) encoder (replaces Pointnet2ClsMSG.forward, pointnet2.py:203-211, and
+ *    _PointnetSAModuleBase.forward, pointnet2_modules.py:19-56).  Features are kept POINT-MAJOR
+ *    [b, n, C] on the device (the reference keeps [b, C, n]).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* FPS + gather for up to 3 consecutive set-abstraction levels in one launch (one workgroup per cloud).
+ * xyz [b,n0,3]; level l selects m[l] points out of the previous level's selection.
+ * idx_l [b,m_l] i32 (indices into the previous level's point list), new_xyz_l [b,m_l,3].  Unused levels: m = 0. */
+int gp_fps_chain(int b, int n0, int nlevels, const int *m, const float *xyz, int32_t *idx0, float *new_xyz0,
+                 int32_t *idx1, float *new_xyz1, int32_t *idx2, float *new_xyz2, gp_stream_t s);
+
+/* Ball query for the two scales of one MSG level in a single pass; rows with no hit are zero-filled. */
+int gp_ball_query_msg(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
+                      const float *xyz, int32_t *idx0, int32_t *idx1, gp_stream_t s);
+
+/* One scale of one set-abstraction level: gather neighbourhood -> 3-layer shared MLP (BN folded, ReLU) on
+ * fp32 MFMA -> max over the neighbourhood.  Never materialises the grouped [b,C+3,np,ns] tensor.
+ *   xyz [b,n,3]; feats_in [b,n,cin] or NULL (cin = 0); new_xyz [b,np,3] and idx [b,np,ns] (grouping mode)
+ *   or new_xyz = idx = NULL with np = 1 (GroupAll mode: ns must equal n, absolute xyz, pointnet2_utils.py:268-291).
+ *   wpack*: weights packed by gp_pack_weight_size/gp_pack_weight (layer input order = [feats..., dx,dy,dz]);
+ *   bias*: folded BN shift per output channel (padded to a multiple of 16).
+ *   out [b,np,cout_total]: this scale writes channels [cout_off, cout_off + c3).
+ * GroupAll mode accumulates with an integer atomic max (post-ReLU values are >= 0): out must be zeroed first. */
+int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3, const float *xyz, const float *feats_in,
+                  const float *new_xyz, const int32_t *idx, const float *wpack1, const float *bias1, const float *wpack2,
+                  const float *bias2, const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off,
+                  gp_stream_t s);
+
+/* Weight packing for the MFMA layers (host-callable helpers operating on HOST memory):
+ * W is [n_out, k_in] row-major (torch Linear / 1x1 conv layout).  Packed size in floats = gp_pack_weight_size(). */
+int64_t gp_pack_weight_size(int n_out, int k_in);
+int gp_pack_weight(int n_out, int k_in, const float *W, int ldw, float *packed);
+
+/* ------------------------------------------------------------------------------------------------
+ * C. Score / energy network and the samplers (scorenet.py:178-222, energynet.py:143-198,
+ *    samplers.py:102-160 PC, samplers.py:163-227 PF-ODE with scipy RK45 semantics).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Parameter block shared by the score/energy entry points (all device pointers). */
+typedef struct gp_scorenet {
+    const float *w_pose0; /* packed [256 x 9]   pose_encoder.0 */
+    const float *b_pose0; /* [256] */
+    const float *w_pose2; /* packed [256 x 256] pose_encoder.2 */
+    const float *b_pose2; /* [256] */
+    const float *w_headx; /* packed [768 x 256]: pose_feat columns of fusion_tail_{rot_x,rot_y,trans}.0 stacked */
+    const float *w_out;   /* [9 x 256]: rows 0-2 rot_x.2, 3-5 rot_y.2, 6-8 trans.2 */
+    const float *b_out;   /* [9] */
+    const float *fourier_w; /* [64] t_encoder.0.W */
+    const float *w_t1;    /* [128 in][128 out]: t_encoder.1.weight TRANSPOSED */
+    const float *b_t1;    /* [128] */
+    const float *w_headt; /* [128 in][768 out]: t_feat columns of the three head first layers, TRANSPOSED */
+    const float *w_headp; /* packed [768 x 1024]: pts_feat columns of the three head first layers */
+    const float *b_head;  /* [768] */
+} gp_scorenet;
+
+/* cvec[b,768] = W_headp . pts_feat[b] + b_head  (hoisted once per cloud; exact algebra). */
+int gp_cloud_embed(int b, const gp_scorenet *net, const float *pts_feat, float *cvec, gp_stream_t s);
+/* tvec[nt,768] = W_headt . relu(W_t1 . fourier(t) + b_t1) for nt time values read from DEVICE memory (f32). */
+int gp_time_embed(int nt, const gp_scorenet *net, const float *t, float *tvec, gp_stream_t s);
+
+/* f_theta / score / energy for R = nclouds*k rows.  x [R,9] f32; tvec [768]; sigma = *sigma_dev (f32).
+ * mode 0: out[R,9] = f_theta/(sigma+1e-7) (score, scorenet.py:217); mode 1: out[R,2] = IP energy (energynet.py:180-185). */
+int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x,
+                  const float *sigma_dev, int mode, float *out, gp_stream_t s);
+
+/* Rows per workgroup tile of the score kernels (size of `partials` = nsteps * ceil(R / tile)). */
+int gp_score_tile_rows(void);
+
+/* One launch of the predictor-corrector sampler (cond_pc_sampler, samplers.py:102-160), score evaluation fused in.
+ * Launch `step` = 0 .. nsteps (nsteps+1 launches, stream order is the only synchronisation):
+ *   step > 0      : finishes step-1 for every row - Langevin corrector with the BATCH-MEAN gradient norm
+ *                   (samplers.py:130-132; reduced in fixed order from partials[step-1][*]), renormalisation (:142-143),
+ *                   Euler-Maruyama predictor with the pre-corrector score (:146-149), normalize_rotation (:152);
+ *   step < nsteps : evaluates score(x, t_step) -> score[R,9] and this tile's sum of row norms -> partials[step][tile];
+ *   step == nsteps: additionally writes mean_x (+centre, normalised: :157-158).
+ * sched [nsteps][4] f32 = {sigma(t_i), g(t_i), step_size, sqrt(step_size)} (host schedule table);
+ * tvec_all [nsteps][768] from gp_time_embed; z_* [nsteps][R][9] standard-normal draws; centre [nclouds][3];
+ * traj: NULL or [nsteps][R][9] (in-process samples, centre added). */
+int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec, const float *tvec_all,
+               const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
+               float *score, float *partials, float *traj, gp_stream_t s);
+
+/* Probability-flow ODE sampler = cond_ode_sampler (samplers.py:163-227) over scipy's RK45 (rk.py / common.py):
+ * Dormand-Prince 5(4), f64 state and controller resident in device memory, f32 score network, batch-global RMS
+ * error norm, SAFETY 0.9 / MIN_FACTOR 0.2 / MAX_FACTOR 10, Hairer initial step.
+ *   state   : opaque device block of gp_rk45_state_bytes() bytes (field offsets: gp_rk45_state_layout)
+ *   y, ynew : [R*9] f64;  K : [7][R*9] f64;  partials : [3][ceil(R/tile)] f64;  tvec : [8][768] f32
+ *   traj    : NULL or [traj_cap][R*9] f64 (accepted states; slot 0 = y0)
+ * gp_rk45_phase launches one fixed, capture-safe sequence per call:
+ *   0 reset(t0 -> t_bound, rtol, atol)   1 f0 + d0,d1 -> h0   2 f1 + d2 -> h_abs, first stage times
+ *   3 ONE attempt: 6 fused stage kernels (stage update + score evaluation) + controller (+ trajectory record);
+ *     a no-op once the device-side status word is non-zero
+ *   4 set evaluation slot 0 to time `t0` (the denoise evaluation at eps)
+ *   5 finish: denoise step (samplers.py:209-218) with scale `denoise_scale`, normalize_rotation, + centre -> x_out [R,9] f64,
+ *     and the same post-processing of the first `nstates` trajectory states.
+ * Before phases 1, 2, every 3 and 5 the caller refreshes tvec = gp_time_embed(8, net, state + offset(stage_t), tvec). */
+int64_t gp_rk45_state_bytes(void);
+int gp_rk45_state_layout(int64_t *offsets, int n); /* n >= 13: t,h_abs,status,n_attempts,n_accepted,nfev,err_norm,log_t,log_h,log_err,log_acc,stage_t,last_accepted */
+int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre,
+                  void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap, double t0,
+                  double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
+                  gp_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * D. Ranking and aggregation (reward.py:131-155, sgpa_utils.py:897-954, evaluation_tracking.py:60-77)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* poses [b,k,9] f32/f64 (is_f64), energy [b,k,2] f32 -> sorted_poses (same dtype), sorted_energy [b,k,2],
+ * order [b,k,2] i32 (stable descending), avg_pose [b,7] f32 (w,x,y,z,tx,ty,tz) over the top `sel` candidates. */
+int gp_rank_aggregate(int b, int k, int sel, int is_f64, const void *poses, const float *energy, void *sorted_poses,
+                      float *sorted_energy, int32_t *order, float *avg_pose, gp_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENPOSE_HIP_H */

@@ -1,0 +1,67 @@
+"""GPU parity: score / energy networks (G4/G5) and the PC sampler (G7) against golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import genpose_oracle as go
+
+# f_theta is O(1), divided by sigma(t) (down to 1e-2): relative tolerance on the score, stated here
+NET_RTOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from genpose_amd.scorenet import ScoreNetHIP
+    return ScoreNetHIP(go.make_state_dict(0, "score"), "cuda"), ScoreNetHIP(go.make_state_dict(0, "energy"), "cuda")
+
+
+def test_score_energy_golden(nets, golden):
+    g = golden("g4_g5_nets.npz")
+    snet, enet = nets
+    pf, pose = torch.from_numpy(g["pts_feat"]).cuda(), torch.from_numpy(g["pose"]).cuda()
+    for i, t in enumerate(g["t"]):
+        tt = torch.ones(8, 1, device="cuda") * float(t)
+        s = snet.forward_rows(pf, pose, tt, "score").cpu().numpy()
+        e = enet.forward_rows(pf, pose, tt, "energy").cpu().numpy()
+        np.testing.assert_allclose(s, g[f"score_{i}"], rtol=NET_RTOL, atol=NET_RTOL * np.abs(g[f"score_{i}"]).max())
+        np.testing.assert_allclose(e, g[f"energy_{i}"], rtol=NET_RTOL, atol=NET_RTOL * np.abs(g[f"energy_{i}"]).max())
+
+
+def test_score_rows_share_cloud_embedding(nets):
+    """cvec hoisting: B clouds x K candidates with one embedding per cloud == per-row evaluation; ragged tile sizes."""
+    snet, _ = nets
+    sd = go.make_state_dict(0, "score")
+    gen = torch.Generator().manual_seed(3)
+    for B, K in [(1, 1), (3, 50), (7, 10), (2, 33)]:
+        pf = torch.randn(B, 1024, generator=gen).abs()
+        pose = torch.randn(B * K, 9, generator=gen)
+        t = 0.3
+        ref = go.score_forward(sd, pf.repeat_interleave(K, 0), pose, torch.ones(B * K, 1) * t).numpy()
+        cvec = snet.cloud_embed(pf.cuda())
+        tvec = snet.time_embed(torch.tensor([t], device="cuda"))
+        sigma = torch.tensor([0.01 * 5000.0 ** t], device="cuda")
+        got = snet.evaluate(cvec, K, pose.cuda(), tvec[0], sigma, "score").cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=NET_RTOL, atol=NET_RTOL * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pc_sampler_golden(nets, golden, use_graph):
+    from genpose_amd.encoder import Pointnet2EncoderHIP
+    from genpose_amd.samplers import PCSampler
+    g = golden("g7_pc.npz")
+    snet, _ = nets
+    sd = go.make_state_dict(0, "score")
+    pts = torch.from_numpy(g["pts"]).cuda()
+    feat = Pointnet2EncoderHIP(sd, "cuda").forward(pts)
+    cvec = snet.cloud_embed(feat)
+    B, K, n = 2, 10, 20
+    smp = PCSampler(snet, B, K, n, "cuda", use_graph=use_graph, record_traj=True)
+    init_x = torch.from_numpy(g["prior_noise"]) * 50.0
+    for _ in range(2):  # second call replays the captured graph
+        xs, mean_x = smp.run(cvec, pts.mean(dim=1), init_x.cuda(), torch.from_numpy(g["z_langevin"]).cuda(),
+                             torch.from_numpy(g["z_predictor"]).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(mean_x.reshape(B, K, 9).cpu().numpy(), g["pred"], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(xs.reshape(B, K, n, 9).cpu().numpy(), g["proc"], rtol=1e-3, atol=5e-3)
