@@ -39,7 +39,7 @@ SIGNATURES = {
     "gp_sa_mlp_max": [c_int] * 8 + [P] * 10 + [P, c_int, c_int, P],
     "gp_pack_weight_size": [c_int, c_int],
     "gp_pack_weight": [c_int, c_int, P, c_int, P],
-    "gp_score_tile_rows": [],
+    "gp_score_tile_rows": [c_int],
     "gp_cloud_embed": [c_int, NETP, P, P, P],
     "gp_time_embed": [c_int, NETP, P, P, P],
     "gp_score_eval": [c_int, c_int, NETP, P, P, P, P, c_int, P, P],
@@ -61,6 +61,7 @@ class GenposeHipError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  torch's bundled libamdhip64.so.7 must be the process's HIP runtime (shared streams/pointers)
         if not os.path.exists(SO_PATH):
             raise GenposeHipError(
                 f"{SO_PATH} is missing - build it with `python -m genpose_amd.build` (hipcc, gfx950). "
@@ -100,6 +101,10 @@ def check_device():
     global _device_checked
     if _device_checked:
         return
+    import torch
+    if not torch.cuda.is_available():
+        raise GenposeHipError("genpose_amd needs an MI355X (gfx950) device; torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.init()
     buf = ctypes.create_string_buffer(64)
     rc = lib().gp_device_arch(buf, 64)
     if rc != 0:

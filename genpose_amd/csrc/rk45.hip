@@ -370,6 +370,61 @@ int set_lds_attr(K kern, size_t lds) {
 
 }  // namespace
 
+template <int P>
+static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double *traj, int traj_cap, double t0, double t_bound, double rtol,
+                           double atol, double denoise_scale, int do_denoise, int nstates, const float *centre, double *x_out, hipStream_t st) {
+    const double *y = a.y;
+    const size_t lds = trunk_lds_bytes<P>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (set_lds_attr(rk45_stage_kernel<P, 0>, lds) || set_lds_attr(rk45_stage_kernel<P, 1>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 2>, lds) || set_lds_attr(rk45_stage_kernel<P, 3>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 4>, lds) || set_lds_attr(rk45_stage_kernel<P, 5>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 6>, lds) || set_lds_attr(rk45_stage_kernel<P, 7>, lds) ||
+            set_lds_attr(rk45_finish_kernel<P>, lds))
+            return GP_ELAUNCH;
+        attr_done = true;
+    }
+    const dim3 grid(a.nblocks), blk(256);
+    const size_t n = (size_t)a.nrows * 9;
+    switch (phase) {
+        case 0:
+            hipLaunchKernelGGL(rk45_reset_kernel, dim3(1), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
+            if (traj && hipMemcpyAsync(traj, y, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return GP_ELAUNCH;
+            break;
+        case 1:
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 0>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 0);
+            break;
+        case 2:
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 7>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 1);
+            break;
+        case 3:
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 1>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 2>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 3>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 4>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 5>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 6>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 2);
+            if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64), blk, 0, st, a);
+            break;
+        case 4:
+            hipLaunchKernelGGL(rk45_set_slot0_kernel, dim3(1), dim3(64), 0, st, a.st, t0);
+            break;
+        case 5:
+            if (!x_out) return GP_EINVAL;
+            hipLaunchKernelGGL((rk45_finish_kernel<P>), grid, blk, lds, st, a, *net, denoise_scale, do_denoise, x_out);
+            if (traj && nstates > 0)
+                hipLaunchKernelGGL(rk45_traj_post_kernel, dim3(128), blk, 0, st, a.nrows, a.kcand, nstates, centre, traj);
+            break;
+        default:
+            return GP_EINVAL;
+    }
+    return gp_launch_status();
+}
+
 extern "C" {
 
 int64_t gp_rk45_state_bytes(void) { return (int64_t)sizeof(Rk45State); }
@@ -397,7 +452,8 @@ int gp_rk45_state_layout(int64_t *out, int n) {
 static int ode_args(OdeArgs *a, int nclouds, int k, const float *cvec, const float *tvec, const float *centre, void *state, double *y,
                     double *ynew, double *K, double *partials, double *traj, float *x32) {
     if (nclouds <= 0 || k <= 0 || !cvec || !tvec || !centre || !state || !y || !ynew || !K || !partials) return GP_EINVAL;
-    a->nrows = nclouds * k, a->kcand = k, a->nblocks = (a->nrows + SCORE_P - 1) / SCORE_P;
+    a->nrows = nclouds * k, a->kcand = k;
+    { const int P = score_tile_rows(a->nrows); a->nblocks = (a->nrows + P - 1) / P; }
     a->cvec = cvec, a->tvec = tvec, a->centre = centre, a->st = (Rk45State *)state;
     a->y = y, a->ynew = ynew, a->K = K, a->partials = partials, a->traj = traj, a->x32 = x32;
     return GP_OK;
@@ -418,56 +474,10 @@ int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const f
     OdeArgs a;
     int rc = ode_args(&a, nclouds, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
     if (rc != GP_OK || !net) return GP_EINVAL;
-    hipStream_t st = (hipStream_t)s;
-    const size_t lds = trunk_lds_bytes<SCORE_P>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (set_lds_attr(rk45_stage_kernel<SCORE_P, 0>, lds) || set_lds_attr(rk45_stage_kernel<SCORE_P, 1>, lds) ||
-            set_lds_attr(rk45_stage_kernel<SCORE_P, 2>, lds) || set_lds_attr(rk45_stage_kernel<SCORE_P, 3>, lds) ||
-            set_lds_attr(rk45_stage_kernel<SCORE_P, 4>, lds) || set_lds_attr(rk45_stage_kernel<SCORE_P, 5>, lds) ||
-            set_lds_attr(rk45_stage_kernel<SCORE_P, 6>, lds) || set_lds_attr(rk45_stage_kernel<SCORE_P, 7>, lds) ||
-            set_lds_attr(rk45_finish_kernel<SCORE_P>, lds))
-            return GP_ELAUNCH;
-        attr_done = true;
-    }
-    const dim3 grid(a.nblocks), blk(256);
-    const size_t n = (size_t)a.nrows * 9;
-    switch (phase) {
-        case 0:
-            hipLaunchKernelGGL(rk45_reset_kernel, dim3(1), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
-            if (traj && hipMemcpyAsync(traj, y, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return GP_ELAUNCH;
-            break;
-        case 1:
-            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 0>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 0);
-            break;
-        case 2:
-            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 7>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 1);
-            break;
-        case 3:
-            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 1>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 2>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 3>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 4>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 5>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<SCORE_P, 6>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 2);
-            if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64), blk, 0, st, a);
-            break;
-        case 4:
-            hipLaunchKernelGGL(rk45_set_slot0_kernel, dim3(1), dim3(64), 0, st, a.st, t0);
-            break;
-        case 5:
-            if (!x_out) return GP_EINVAL;
-            hipLaunchKernelGGL((rk45_finish_kernel<SCORE_P>), grid, blk, lds, st, a, *net, denoise_scale, do_denoise, x_out);
-            if (traj && nstates > 0)
-                hipLaunchKernelGGL(rk45_traj_post_kernel, dim3(128), blk, 0, st, a.nrows, a.kcand, nstates, centre, traj);
-            break;
-        default:
-            return GP_EINVAL;
-    }
-    return gp_launch_status();
+    return score_tile_rows(a.nrows) == 16 ? rk45_phase_impl<16>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise,
+                                                                nstates, centre, x_out, (hipStream_t)s)
+                                         : rk45_phase_impl<32>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise,
+                                                                nstates, centre, x_out, (hipStream_t)s);
 }
 
 }  // extern "C"

@@ -7,6 +7,8 @@
 //   gather rows into LDS  [P][K0pad+8]   (feature columns first, then dx,dy,dz, zero pad)
 //   layer 1: LDS A -> LDS B,  layer 2: LDS B -> LDS A,  layer 3: LDS A -> registers -> max -> global.
 // Weights stream from L2 straight into MFMA A-operand registers (host-packed fragment order, gp_common.h).
+#include <stdlib.h>
+
 #include "gp_common.h"
 
 namespace {
@@ -174,6 +176,12 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
         return GP_EINVAL;
     }
     if (ns > 64) return GP_EINVAL;
+    static int forced = -1;  // GP_SA_P = 32 | 64 (tuning override)
+    if (forced < 0) {
+        const char *e = getenv("GP_SA_P");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 32 && ns <= 32) return launch<32, 4, 4>(a, b, st);
     if (lds_bytes(64, a) <= 150 * 1024) return launch<64, 4, 4>(a, b, st);
     if (ns <= 32) return launch<32, 4, 4>(a, b, st);
     return GP_EINVAL;

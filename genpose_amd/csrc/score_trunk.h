@@ -1,5 +1,7 @@
 // Shared trunk of PoseScoreNet / PoseEnergyNet for one tile of pose rows (included by scorenet.hip and rk45.hip).
 #pragma once
+#include <stdlib.h>
+
 #include "gp_common.h"
 
 namespace gp_trunk {
@@ -105,7 +107,17 @@ constexpr size_t trunk_lds_bytes() {
     return (size_t)TrunkLds<P>::TOTAL * sizeof(float);
 }
 
-constexpr int SCORE_P = 32;
+// Rows per workgroup tile: 32 when that still gives >= 1.5 workgroups per CU, else 16 (fills more of the 256 CUs:
+// the kernels are MFMA-bound per CU, so small batches want more, smaller tiles).  GP_SCORE_P overrides (tuning).
+static inline int score_tile_rows(int nrows) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("GP_SCORE_P");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 16 || forced == 32) return forced;
+    return ((nrows + 31) / 32 >= 384) ? 32 : 16;
+}
 
 // Gram-Schmidt of pytorch3d.rotation_6d_to_matrix + GenPose's column write-back (utils/misc.py:259-265):
 // b1 = a1/max(|a1|,1e-12); b2 = a2 - (b1.a2) b1; b2 /= max(|b2|,1e-12)

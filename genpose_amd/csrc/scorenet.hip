@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void pc_step_kernel(PcArgs a, gp_scorenet n
 
 extern "C" {
 
-int gp_score_tile_rows(void) { return SCORE_P; }
+int gp_score_tile_rows(int nrows) { return score_tile_rows(nrows); }
 
 int gp_cloud_embed(int b, const gp_scorenet *net, const float *pts_feat, float *cvec, gp_stream_t s) {
     if (b < 0 || !net || !pts_feat || !cvec) return GP_EINVAL;
@@ -258,16 +258,22 @@ int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec,
     if (nclouds < 0 || k <= 0 || !net || !cvec || !tvec || !x || !sigma_dev || !out || (mode != 0 && mode != 1)) return GP_EINVAL;
     const int R = nclouds * k;
     if (R == 0) return GP_OK;
-    auto kern = score_eval_kernel<SCORE_P>;
-    const size_t lds = trunk_lds_bytes<SCORE_P>();
+    const int P = score_tile_rows(R);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(score_eval_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)trunk_lds_bytes<16>()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(score_eval_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)trunk_lds_bytes<32>()) != hipSuccess)
             return GP_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((R + SCORE_P - 1) / SCORE_P), dim3(256), lds, (hipStream_t)s, R, k, *net, cvec, tvec, x, sigma_dev, mode,
-                       out);
+    if (P == 16)
+        hipLaunchKernelGGL(score_eval_kernel<16>, dim3((R + 15) / 16), dim3(256), trunk_lds_bytes<16>(), (hipStream_t)s, R, k, *net, cvec, tvec,
+                           x, sigma_dev, mode, out);
+    else
+        hipLaunchKernelGGL(score_eval_kernel<32>, dim3((R + 31) / 32), dim3(256), trunk_lds_bytes<32>(), (hipStream_t)s, R, k, *net, cvec, tvec,
+                           x, sigma_dev, mode, out);
     return gp_launch_status();
 }
 
@@ -280,18 +286,23 @@ int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net,
     const int R = nclouds * k;
     if (R == 0) return GP_OK;
     PcArgs a;
-    a.nrows = R, a.kcand = k, a.step = step, a.nsteps = nsteps, a.nblocks = (R + SCORE_P - 1) / SCORE_P;
+    const int P = score_tile_rows(R);
+    a.nrows = R, a.kcand = k, a.step = step, a.nsteps = nsteps, a.nblocks = (R + P - 1) / P;
     a.cvec = cvec, a.tvec_all = tvec_all, a.sched = sched, a.z_lang = z_langevin, a.z_pred = z_predictor, a.centre = centre;
     a.x = x, a.mean_x = mean_x, a.score = score, a.partials = partials, a.traj = traj;
-    auto kern = pc_step_kernel<SCORE_P>;
-    const size_t lds = trunk_lds_bytes<SCORE_P>();
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pc_step_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)trunk_lds_bytes<16>()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(pc_step_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)trunk_lds_bytes<32>()) != hipSuccess)
             return GP_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), lds, (hipStream_t)s, a, *net);
+    if (P == 16)
+        hipLaunchKernelGGL(pc_step_kernel<16>, dim3(a.nblocks), dim3(256), trunk_lds_bytes<16>(), (hipStream_t)s, a, *net);
+    else
+        hipLaunchKernelGGL(pc_step_kernel<32>, dim3(a.nblocks), dim3(256), trunk_lds_bytes<32>(), (hipStream_t)s, a, *net);
     return gp_launch_status();
 }
 

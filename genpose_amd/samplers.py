@@ -30,7 +30,7 @@ class PCSampler:
         self.dev = torch.device(device)
         R = B * K
         self.R = R
-        self.tile = _lib.lib().gp_score_tile_rows()
+        self.tile = _lib.lib().gp_score_tile_rows(R)
         self.nblocks = (R + self.tile - 1) // self.tile
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)
@@ -106,7 +106,7 @@ class ODESampler:
         self.net, self.B, self.K = net, B, K
         self.dev = torch.device(device)
         R = self.R = B * K
-        self.tile = _lib.lib().gp_score_tile_rows()
+        self.tile = _lib.lib().gp_score_tile_rows(R)
         self.nblocks = (R + self.tile - 1) // self.tile
         self.layout, nbytes = _state_layout()
         self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)

@@ -135,7 +135,7 @@ int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec,
                   const float *sigma_dev, int mode, float *out, gp_stream_t s);
 
 /* Rows per workgroup tile of the score kernels (size of `partials` = nsteps * ceil(R / tile)). */
-int gp_score_tile_rows(void);
+int gp_score_tile_rows(int nrows);
 
 /* One launch of the predictor-corrector sampler (cond_pc_sampler, samplers.py:102-160), score evaluation fused in.
  * Launch `step` = 0 .. nsteps (nsteps+1 launches, stream order is the only synchronisation):
