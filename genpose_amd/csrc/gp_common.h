@@ -9,13 +9,29 @@ static inline int gp_launch_status() { return hipGetLastError() == hipSuccess ? 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Phase timestamps for tuning builds (python -m genpose_amd.build with GP_TIMING=1): block 0, lane 0 of every wave.
+#ifdef GP_TIMING
+extern __device__ unsigned long long gp_dbg_ts[4 * 32];
+#define GP_T(i)                                                                                          \
+    do {                                                                                                 \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) gp_dbg_ts[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GP_T(i) \
+    do {        \
+    } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // fp32 MFMA building block: Y^T[N, P] = W[N, K] . X^T[K, P]  on v_mfma_f32_16x16x4_f32
 // (exact f32: bitwise a k-ordered fmaf chain, 157 TFLOP/s chip peak - MI355X_MICROARCH.md).
 //
 //  A operand = weights.  Packed on the host (gp_pack_weight) so that ONE coalesced global_load_dwordx4
 //  per lane feeds four consecutive MFMAs:
-//      Wp[((nc*KG + kg)*64 + lane)*4 + jj] = W[nc*16 + (lane&15)][kg*16 + 4*(lane>>4) + jj]
+//      Wp[((kg*NC + nc)*64 + lane)*4 + jj] = W[nc*16 + (lane&15)][kg*16 + 4*(lane>>4) + jj]
+//  (k-group major: the 16-channel chunks of one k-group are CONTIGUOUS, so the waves of a workgroup - and the ~200
+//  workgroups that stream the same weights in near lock-step - sweep contiguous memory and spread over all L2 channels;
+//  measured equal to chunk-major on MI355X, kept for the contiguous sweep)
 //  B operand = activations in LDS, row-major [point][k] with row stride ld = Kpad + 8 floats
 //  (ld = 8*odd -> the ds_read_b128 of 16 rows x 4 k-quads is bank-conflict free):
 //      lane reads X[p0 + (lane&15)][kg*16 + 4*(lane>>4) .. +3]
@@ -27,63 +43,140 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ static inline int gp_round16(int v) { return (v + 15) & ~15; }
 
-// One wave: NTB n-chunks x PT p-chunks of 16x16 outputs, full K loop.
+// One wave: NV (<= 4) n-chunks x PT p-chunks of 16x16 outputs, full K loop.
 //   Xs: LDS activations, ld floats per row; pc0: first p-chunk of this wave
-//   Wp: packed weights; KG k-groups; nc[i]: the NTB n-chunk indices (wave-uniform; < 0 = unused)
-template <int NTB, int PT>
-__device__ __forceinline__ void mfma_tile(const float *Xs, int ld, int pc0, const float *__restrict__ Wp, int KG, const int (&nc)[NTB],
-                                          f32x4 (&acc)[NTB][PT]) {
+//   Wp: packed weights; KG k-groups; NC chunks per k-group; nc[i]: n-chunk indices (wave-uniform), i < NV
+// Software pipeline: three register stages, fragments for k-group kg+2 are requested while kg is multiplied
+// (L2 latency ~ 500-800 cycles vs 128*NV*PT MFMA cycles per k-group).  The stage index is static (unroll by 3), so no
+// register rotation copies are needed, and sched_barrier keeps the requests ABOVE the MFMA block (hipcc otherwise
+// sinks loads next to their first use and the counted s_waitcnt degenerates to vmcnt(0)).
+// mfma_preload() may be issued EARLY (before the producing layer's epilogue / barrier) to hide the cold start.
+template <int NV>
+struct WStages {
+    f32x4 w[3][NV];
+};
+
+template <int NV>
+__device__ __forceinline__ void mfma_preload(WStages<NV> &st, const float *__restrict__ Wp, int KG, int NC, const int (&nc)[4]) {
+    const int lane = threadIdx.x & 63;
+    const size_t kstride = (size_t)NC * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int k0 = d < KG ? d : KG - 1;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) st.w[d][i] = (reinterpret_cast<const f32x4 *>(Wp) + (size_t)nc[i] * 64 + lane)[(size_t)k0 * kstride];
+    }
+}
+
+template <int NV, int PT>
+__device__ __forceinline__ void mfma_run(WStages<NV> &st, const float *Xs, int ld, int pc0, const float *__restrict__ Wp, int KG, int NC,
+                                         const int (&nc)[4], f32x4 (&acc)[4][PT]) {
     const int lane = threadIdx.x & 63;
     const float *xrow[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) xrow[p] = Xs + ((pc0 + p) * 16 + (lane & 15)) * ld + 4 * (lane >> 4);
-    const f32x4 *wp[NTB];
+    const f32x4 *wp[NV];
 #pragma unroll
-    for (int i = 0; i < NTB; ++i) wp[i] = reinterpret_cast<const f32x4 *>(Wp) + ((size_t)(nc[i] < 0 ? 0 : nc[i]) * KG) * 64 + lane;
+    for (int i = 0; i < NV; ++i) wp[i] = reinterpret_cast<const f32x4 *>(Wp) + (size_t)nc[i] * 64 + lane;
+    const size_t kstride = (size_t)NC * 64;  // f32x4 units between consecutive k-groups
 #pragma unroll
-    for (int i = 0; i < NTB; ++i)
+    for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int p = 0; p < PT; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 wn[NTB];
+    f32x4 xq[3][PT];
 #pragma unroll
-    for (int i = 0; i < NTB; ++i) wn[i] = wp[i][0];
-    for (int kg = 0; kg < KG; ++kg) {
-        f32x4 w[NTB], x[PT];
+    for (int d = 0; d < 2; ++d) {
+        const int k0 = d < KG ? d : KG - 1;
 #pragma unroll
-        for (int i = 0; i < NTB; ++i) w[i] = wn[i];
-        if (kg + 1 < KG) {
+        for (int p = 0; p < PT; ++p) xq[d][p] = *reinterpret_cast<const f32x4 *>(xrow[p] + k0 * 16);
+    }
+    // main loop: whole triples, branch-free body (clamped prefetch index: the last two requests re-read the final
+    // k-group, harmless) so that the compiler's s_waitcnt counts stay exact: vmcnt(2*NV) = "two stages still in flight"
+    int kg = 0;
+#pragma unroll 1
+    for (; kg + 3 <= KG; kg += 3) {
 #pragma unroll
-            for (int i = 0; i < NTB; ++i) wn[i] = wp[i][(size_t)(kg + 1) * 64];
+        for (int d = 0; d < 3; ++d) {
+            const int nxt = (kg + d + 2 < KG) ? kg + d + 2 : KG - 1;
+            const int e = (d + 2) % 3;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) st.w[e][i] = wp[i][(size_t)nxt * kstride];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) xq[e][p] = *reinterpret_cast<const f32x4 *>(xrow[p] + nxt * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p)
+                        acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.w[d][i][jj], xq[d][p][jj], acc[i][p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    // tail: KG % 3 k-groups, already resident in stages 0 (and 1)
 #pragma unroll
-        for (int p = 0; p < PT; ++p) x[p] = *reinterpret_cast<const f32x4 *>(xrow[p] + kg * 16);
+    for (int d = 0; d < 2; ++d) {
+        if (kg + d < KG) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int i = 0; i < NTB; ++i)
+                for (int i = 0; i < NV; ++i)
 #pragma unroll
-                for (int p = 0; p < PT; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][jj], x[p][jj], acc[i][p], 0, 0, 0);
+                    for (int p = 0; p < PT; ++p)
+                        acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.w[d][i][jj], xq[d][p][jj], acc[i][p], 0, 0, 0);
+        }
     }
 }
 
+template <int NV, int PT>
+__device__ __forceinline__ void mfma_tile(const float *Xs, int ld, int pc0, const float *__restrict__ Wp, int KG, int NC, const int (&nc)[4],
+                                          f32x4 (&acc)[4][PT]) {
+    WStages<NV> st;
+    mfma_preload<NV>(st, Wp, KG, NC, nc);
+    mfma_run<NV, PT>(st, Xs, ld, pc0, Wp, KG, NC, nc, acc);
+}
+
+// nv-dispatching wrapper: only the valid n-chunks are computed (no wasted MFMAs on ragged channel counts)
+template <int PT>
+__device__ __forceinline__ void mfma_tile_n(int nv, const float *Xs, int ld, int pc0, const float *__restrict__ Wp, int KG, int NC,
+                                            const int (&nc)[4], f32x4 (&acc)[4][PT]) {
+    switch (nv) {
+        case 1: mfma_tile<1, PT>(Xs, ld, pc0, Wp, KG, NC, nc, acc); break;
+        case 2: mfma_tile<2, PT>(Xs, ld, pc0, Wp, KG, NC, nc, acc); break;
+        case 3: mfma_tile<3, PT>(Xs, ld, pc0, Wp, KG, NC, nc, acc); break;
+        default: mfma_tile<4, PT>(Xs, ld, pc0, Wp, KG, NC, nc, acc); break;
+    }
+}
+
+// Wave arrangement for a layer with NC output chunks on a P-point tile: WN waves along channels x (4/WN) along points,
+// chosen so that every wave gets >= 4 chunks when possible (narrow layers tile the POINT dimension instead).
+__device__ __forceinline__ int pick_wn(int NC, int P, int min_pts) {
+    int wn = NC >= 16 ? 4 : (NC >= 8 ? 2 : 1);
+    while (wn < 4 && (P * wn / 4 < 16 || P * wn / 4 < min_pts)) wn *= 2;  // each wave needs >= 16 (and >= min_pts) points
+    return wn;
+}
+
 // Dense layer over a P-point LDS tile: out = relu(X W^T + bias) written back to LDS (row stride ldo).
-// Waves are arranged WN (along channels) x WP (along points); each wave owns PT p-chunks.
-template <int NTB, int PT, int WN, bool RELU>
-__device__ __forceinline__ void dense_to_lds(const float *Xs, int ld, const float *__restrict__ Wp, const float *__restrict__ bias, int K,
-                                             int N, float *Ys, int ldo) {
+template <int PT, int WN, bool RELU>
+__device__ __forceinline__ void dense_to_lds_w(const float *Xs, int ld, const float *__restrict__ Wp, const float *__restrict__ bias, int K,
+                                               int N, float *Ys, int ldo) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wn = wave % WN, wp = wave / WN;
     const int KG = gp_round16(K) / 16, NC = gp_round16(N) / 16;
     const int pc0 = wp * PT;
-    for (int ncb = wn; ncb < NC; ncb += WN * NTB) {
-        int nc[NTB];
+    for (int ncb = wn; ncb < NC; ncb += WN * 4) {
+        int nc[4], nv = 0;
 #pragma unroll
-        for (int i = 0; i < NTB; ++i) nc[i] = (ncb + i * WN < NC) ? ncb + i * WN : -1;
-        f32x4 acc[NTB][PT];
-        mfma_tile<NTB, PT>(Xs, ld, pc0, Wp, KG, nc, acc);
+        for (int i = 0; i < 4; ++i) {
+            nc[i] = ncb + i * WN;
+            nv += nc[i] < NC;
+        }
+        f32x4 acc[4][PT];
+        mfma_tile_n<PT>(nv, Xs, ld, pc0, Wp, KG, NC, nc, acc);
 #pragma unroll
-        for (int i = 0; i < NTB; ++i) {
-            if (nc[i] < 0) continue;
+        for (int i = 0; i < 4; ++i) {
+            if (i >= nv) break;
             const int ch = nc[i] * 16 + 4 * (lane >> 4);
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + ch);
 #pragma unroll
@@ -99,6 +192,37 @@ __device__ __forceinline__ void dense_to_lds(const float *Xs, int ld, const floa
             }
         }
     }
+}
+
+// P-point tile, wave arrangement picked per layer at run time.
+template <int P, bool RELU>
+__device__ __forceinline__ void dense_to_lds(const float *Xs, int ld, const float *__restrict__ Wp, const float *__restrict__ bias, int K, int N,
+                                             float *Ys, int ldo) {
+    const int wn = pick_wn(gp_round16(N) / 16, P, 16);
+    if constexpr (P >= 64) {
+        if (wn == 1) return dense_to_lds_w<P / 64, 1, RELU>(Xs, ld, Wp, bias, K, N, Ys, ldo);
+    }
+    if constexpr (P >= 32) {
+        if (wn == 2) return dense_to_lds_w<P / 32, 2, RELU>(Xs, ld, Wp, bias, K, N, Ys, ldo);
+    }
+    return dense_to_lds_w<P / 16, 4, RELU>(Xs, ld, Wp, bias, K, N, Ys, ldo);
+}
+
+// Wave-wide float sum on DPP row operations (VALU speed, fixed order -> deterministic); result valid in EVERY lane
+// (read back from lane 63 as a wave-uniform scalar).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+    return v + o;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v = dpp_add_f32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add_f32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add_f32<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_add_f32<0x140, 0xF>(v);  // row_mirror: every lane of a row holds the row sum
+    v = dpp_add_f32<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3 (+ previous row's sum; other rows add 0)
+    v = dpp_add_f32<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // max over the 16 lanes that share (lane >> 4): the 16 points of one p-chunk

@@ -30,13 +30,29 @@ __device__ __forceinline__ uint32_t fkey(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        unsigned long long o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+// Wave-wide max of a u32 with DPP row operations (VALU speed; no LDS crossbar traffic): quad swaps, row mirrors, then
+// row_bcast15 / row_bcast31 accumulate into lane 63, which is read back as a wave-uniform scalar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = dpp_max_u32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_max_u32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_max_u32<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_max_u32<0x140, 0xF>(v);  // row_mirror -> every lane of a 16-lane row holds the row max
+    v = dpp_max_u32<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
+    v = dpp_max_u32<0x143, 0xC>(v);  // row_bcast31 into rows 2,3 -> lane 63 holds the wave max
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Wave-wide max of the packed FPS key (hi = distance key, lo = tie rank) in two 32-bit passes:
+// max distance first, then the max rank among the lanes that hold it.
+__device__ __forceinline__ unsigned long long wave_max_key(uint32_t dkey, uint32_t rank) {
+    const uint32_t m = wave_max_u32(dkey);
+    const uint32_t r = wave_max_u32(dkey == m ? rank : 0u);
+    return ((unsigned long long)m << 32) | r;
 }
 
 constexpr int FPS_T = 256;       // threads per cloud
@@ -94,7 +110,7 @@ __device__ void fps_pass(int n, int m, const float *sx, const float *sy, const f
     if (tid == 0) idx_out[0] = 0;
     for (int it = 1; it < m; ++it) {
         float x1 = sx[old], y1 = sy[old], z1 = sz[old];
-        unsigned long long best = 0ull;
+        uint32_t bd = 0u, br = 0u;  // thread-local best (distance key, rank); valid keys are >= 0x80000000
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             int k = tid + j * FPS_T;
@@ -102,11 +118,13 @@ __device__ void fps_pass(int n, int m, const float *sx, const float *sy, const f
                 float d = sqdist(px[j], py[j], pz[j], x1, y1, z1);
                 float d2 = fminf(d, tmp[j]);
                 tmp[j] = d2;
-                unsigned long long key = ((unsigned long long)fkey(d2) << 32) | rnk[j];
-                best = key > best ? key : best;
+                const uint32_t dk = fkey(d2);
+                const bool better = dk > bd || (dk == bd && rnk[j] > br);
+                bd = better ? dk : bd;
+                br = better ? rnk[j] : br;
             }
         }
-        best = wave_max_u64(best);
+        const unsigned long long best = wave_max_key(bd, br);
         const int par = it & 1;
         if ((tid & 63) == 0) slots[par][tid >> 6] = best;
         __syncthreads();
@@ -137,15 +155,17 @@ __device__ void fps_pass_big(int n, int m, const float *xyz, float *temp, int32_
     if (tid == 0) idx_out[0] = 0;
     for (int it = 1; it < m; ++it) {
         float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
-        unsigned long long best = 0ull;
+        uint32_t bd = 0u, br = 0u;
         for (int k = tid; k < n; k += FPS_T) {
             float d = sqdist(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], x1, y1, z1);
             float d2 = fminf(d, temp[k]);
             temp[k] = d2;
-            unsigned long long key = ((unsigned long long)fkey(d2) << 32) | rk.rank(k);
-            best = key > best ? key : best;
+            const uint32_t dk = fkey(d2), rr = rk.rank(k);
+            const bool better = dk > bd || (dk == bd && rr > br);
+            bd = better ? dk : bd;
+            br = better ? rr : br;
         }
-        best = wave_max_u64(best);
+        const unsigned long long best = wave_max_key(bd, br);
         const int par = it & 1;
         if ((tid & 63) == 0) slots[par][tid >> 6] = best;
         __syncthreads();

@@ -92,6 +92,8 @@ __global__ __launch_bounds__(256, 2) void rk45_stage_kernel(OdeArgs a, gp_scoren
     if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
     const size_t n = (size_t)a.nrows * 9;
     const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
+    TrunkPre pre;
+    trunk_begin<P>(net, pre);
     const double h = st->h;
     if (tid < P) {
         const bool live = row0 + tid < a.nrows;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void rk45_stage_kernel(OdeArgs a, gp_scoren
         for (int j = 9; j < 16; ++j) xr[j] = 0.f;
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, a.tvec + (size_t)slot * HEADS, row0, a.nrows, a.kcand);
+    trunk_ftheta<P>(lds, net, a.cvec, a.tvec + (size_t)slot * HEADS, row0, a.nrows, a.kcand, pre);
     const float sigma = st->stage_sigma[slot];
     const double g2 = st->stage_g2[slot];
     const float *F = lds + L::OFF_H1;
@@ -293,6 +295,8 @@ __global__ __launch_bounds__(256, 2) void rk45_finish_kernel(OdeArgs a, gp_score
     const int row0 = blockIdx.x * P, tid = threadIdx.x;
     const Rk45State *st = a.st;
     const double *yfin = st->last_accepted ? a.ynew : a.y;
+    TrunkPre pre;
+    trunk_begin<P>(net, pre);
     if (tid < P) {
         const int r = row0 + tid < a.nrows ? row0 + tid : a.nrows - 1;
         float *xr = lds + tid * L::LD0;
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void rk45_finish_kernel(OdeArgs a, gp_score
         for (int j = 9; j < 16; ++j) xr[j] = 0.f;
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, a.tvec, row0, a.nrows, a.kcand);  // slot 0 = eps
+    trunk_ftheta<P>(lds, net, a.cvec, a.tvec, row0, a.nrows, a.kcand, pre);  // slot 0 = eps
     const float sigma = st->stage_sigma[0];
     const float *F = lds + L::OFF_H1;
     if (tid < P && row0 + tid < a.nrows) {

@@ -22,13 +22,65 @@ struct SAArgs {
     int cout_total, cout_off, groupall;
 };
 
-template <int P, int WN, int NTB>
+// layer 3 + max over the neighbourhood, straight from the accumulators (WN waves along channels, PT p-chunks per wave)
+template <int PT, int WN>
+__device__ __forceinline__ void layer3_max(const SAArgs &a, const float *A, int lda, int c2p, int row0, int b) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave % WN, wp = wave / WN;
+    const int KG = c2p / 16, NC = gp_round16(a.c3) / 16;
+    const int pc0 = wp * PT;
+    const int G = a.groupall ? PT : a.ns / 16;  // p-chunks per centre
+    float *outb = a.out + (size_t)b * a.np * a.cout_total + a.cout_off;
+    for (int ncb = wn; ncb < NC; ncb += WN * 4) {
+        int nc[4], nv = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            nc[i] = ncb + i * WN;
+            nv += nc[i] < NC;
+        }
+        f32x4 acc[4][PT];
+        mfma_tile_n<PT>(nv, A, lda, pc0, a.w3, KG, NC, nc, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= nv) break;
+            const int ch = nc[i] * 16 + 4 * (lane >> 4);
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b3 + ch);
+            f32x4 m = {0.f, 0.f, 0.f, 0.f};  // ReLU output is >= 0
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                f32x4 v = acc[i][p] + bv;
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+                if ((p + 1) % G == 0) {
+                    m.x = row16_max(m.x);
+                    m.y = row16_max(m.y);
+                    m.z = row16_max(m.z);
+                    m.w = row16_max(m.w);
+                    if ((lane & 15) == 0 && ch < a.c3) {
+                        if (a.groupall) {
+                            unsigned int *o = reinterpret_cast<unsigned int *>(outb + ch);
+                            atomicMax(o + 0, __float_as_uint(m.x));
+                            atomicMax(o + 1, __float_as_uint(m.y));
+                            atomicMax(o + 2, __float_as_uint(m.z));
+                            atomicMax(o + 3, __float_as_uint(m.w));
+                        } else {
+                            const int centre = (row0 + (pc0 + p + 1 - G) * 16) / a.ns;
+                            if (centre < a.np) *reinterpret_cast<f32x4 *>(outb + (size_t)centre * a.cout_total + ch) = m;
+                        }
+                    }
+                    m = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+}
+
+template <int P>
 __global__ __launch_bounds__(256) void sa_mlp_kernel(SAArgs a) {
-    constexpr int WP = 4 / WN;
-    constexpr int PT = P / 16 / WP;
-    static_assert(PT >= 1 && PT * 16 * WP == P, "tile shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int b = blockIdx.y, row0 = blockIdx.x * P;
     const int K0 = a.cin + 3, K0p = gp_round16(K0);
     const int c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
@@ -71,68 +123,28 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SAArgs a) {
         }
     }
     __syncthreads();
-    dense_to_lds<NTB, PT, WN, true>(A, lda, a.w1, a.b1, K0, a.c1, Bf, ldb);
+    dense_to_lds<P, true>(A, lda, a.w1, a.b1, K0, a.c1, Bf, ldb);
     __syncthreads();
-    dense_to_lds<NTB, PT, WN, true>(Bf, ldb, a.w2, a.b2, a.c1, a.c2, A, lda);
+    dense_to_lds<P, true>(Bf, ldb, a.w2, a.b2, a.c1, a.c2, A, lda);
     __syncthreads();
-    // ---- layer 3 + max over the neighbourhood, straight from the accumulators
-    {
-        const int wn = wave % WN, wp = wave / WN;
-        const int KG = c2p / 16, NC = gp_round16(a.c3) / 16;
-        const int pc0 = wp * PT;
-        const int G = a.groupall ? PT : a.ns / 16;  // p-chunks per centre
-        float *outb = a.out + (size_t)b * a.np * a.cout_total + a.cout_off;
-        for (int ncb = wn; ncb < NC; ncb += WN * NTB) {
-            int nc[NTB];
-#pragma unroll
-            for (int i = 0; i < NTB; ++i) nc[i] = (ncb + i * WN < NC) ? ncb + i * WN : -1;
-            f32x4 acc[NTB][PT];
-            mfma_tile<NTB, PT>(A, lda, pc0, a.w3, KG, nc, acc);
-#pragma unroll
-            for (int i = 0; i < NTB; ++i) {
-                if (nc[i] < 0) continue;
-                const int ch = nc[i] * 16 + 4 * (lane >> 4);
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.b3 + ch);
-                f32x4 m = {0.f, 0.f, 0.f, 0.f};  // ReLU output is >= 0
-#pragma unroll
-                for (int p = 0; p < PT; ++p) {
-                    f32x4 v = acc[i][p] + bv;
-                    m.x = fmaxf(m.x, v.x);
-                    m.y = fmaxf(m.y, v.y);
-                    m.z = fmaxf(m.z, v.z);
-                    m.w = fmaxf(m.w, v.w);
-                    if ((p + 1) % G == 0) {
-                        m.x = row16_max(m.x);
-                        m.y = row16_max(m.y);
-                        m.z = row16_max(m.z);
-                        m.w = row16_max(m.w);
-                        if ((lane & 15) == 0 && ch < a.c3) {
-                            if (a.groupall) {
-                                unsigned int *o = reinterpret_cast<unsigned int *>(outb + ch);
-                                atomicMax(o + 0, __float_as_uint(m.x));
-                                atomicMax(o + 1, __float_as_uint(m.y));
-                                atomicMax(o + 2, __float_as_uint(m.z));
-                                atomicMax(o + 3, __float_as_uint(m.w));
-                            } else {
-                                const int centre = (row0 + (pc0 + p + 1 - G) * 16) / a.ns;
-                                if (centre < a.np) *reinterpret_cast<f32x4 *>(outb + (size_t)centre * a.cout_total + ch) = m;
-                            }
-                        }
-                        m = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-            }
-        }
+    // a wave must own whole neighbourhoods for the in-register max: >= ns points per wave (GroupAll: any split, atomics combine)
+    const int wn = pick_wn(gp_round16(a.c3) / 16, P, a.groupall ? 16 : a.ns);
+    if constexpr (P >= 64) {
+        if (wn == 1) return layer3_max<P / 64, 1>(a, A, lda, c2p, row0, b);
     }
+    if constexpr (P >= 32) {
+        if (wn == 2) return layer3_max<P / 32, 2>(a, A, lda, c2p, row0, b);
+    }
+    layer3_max<P / 16, 4>(a, A, lda, c2p, row0, b);
 }
 
-template <int P, int WN, int NTB>
+template <int P>
 int launch(const SAArgs &a, int b, hipStream_t st) {
     const int K0p = gp_round16(a.cin + 3), c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
     const int lda = (K0p > c2p ? K0p : c2p) + GP_LD_PAD, ldb = c1p + GP_LD_PAD;
     const size_t lds = (size_t)P * (lda + ldb) * sizeof(float);
     if (lds > 160 * 1024) return GP_EINVAL;
-    auto kern = sa_mlp_kernel<P, WN, NTB>;
+    auto kern = sa_mlp_kernel<P>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return GP_ELAUNCH;
@@ -166,24 +178,16 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
     SAArgs a{n, np, ns, cin, c1, c2, c3, xyz, feats_in, new_xyz, idx, wpack1, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off,
              groupall ? 1 : 0};
     hipStream_t st = (hipStream_t)s;
-    if (groupall) return launch<32, 4, 4>(a, b, st);
-    const int wide = (c1 > 64 || c2 > 64 || c3 > 64);
-    if (!wide) {
-        // narrow layers (SA level 0): waves tile the POINT dimension so none idles on a 16-channel layer
-        if (ns == 16) return launch<64, 1, 2>(a, b, st);
-        if (ns == 32) return launch<64, 2, 2>(a, b, st);
-        if (ns == 64) return launch<64, 4, 2>(a, b, st);
-        return GP_EINVAL;
-    }
-    if (ns > 64) return GP_EINVAL;
+    if (!groupall && ns > 64) return GP_EINVAL;
     static int forced = -1;  // GP_SA_P = 32 | 64 (tuning override)
     if (forced < 0) {
         const char *e = getenv("GP_SA_P");
         forced = e ? atoi(e) : 0;
     }
-    if (forced == 32 && ns <= 32) return launch<32, 4, 4>(a, b, st);
-    if (lds_bytes(64, a) <= 150 * 1024) return launch<64, 4, 4>(a, b, st);
-    if (ns <= 32) return launch<32, 4, 4>(a, b, st);
+    // 32-row tiles keep 2-3 workgroups per CU resident (gather of one overlaps the MFMA phase of another); measured
+    // faster than 64-row tiles on every level of the light config.  ns = 64 needs 64 rows (one wave owns a neighbourhood).
+    if (groupall || (ns <= 32 && forced != 64)) return launch<32>(a, b, st);
+    if (lds_bytes(64, a) <= 150 * 1024) return launch<64>(a, b, st);
     return GP_EINVAL;
 }
 
@@ -197,7 +201,7 @@ int gp_pack_weight(int n_out, int k_in, const float *W, int ldw, float *packed) 
             for (int lane = 0; lane < 64; ++lane)
                 for (int jj = 0; jj < 4; ++jj) {
                     const int n = nc * 16 + (lane & 15), k = kg * 16 + 4 * (lane >> 4) + jj;
-                    packed[(((size_t)nc * KG + kg) * 64 + lane) * 4 + jj] = (n < n_out && k < k_in) ? W[(size_t)n * ldw + k] : 0.f;
+                    packed[(((size_t)kg * NC + nc) * 64 + lane) * 4 + jj] = (n < n_out && k < k_in) ? W[(size_t)n * ldw + k] : 0.f;
                 }
     return GP_OK;
 }

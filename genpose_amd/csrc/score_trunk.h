@@ -9,27 +9,91 @@ namespace gp_trunk {
 constexpr int HID = 256, HEADS = 768, POSE = 9;
 
 // ---------------------------------------------------------------------------------------------- trunk
-// LDS layout for a P-row tile (floats):  X0 [P][16+8] | H1 [P][256+8] | H2 [P][256+8] | red [4][P][12]
+// LDS layout for a P-row tile (floats):  X0 [P][16+8] | H1 [P][256+8] | H2 [P][256+8] | red [16][P][12]
 template <int P>
 struct TrunkLds {
     static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD;
-    static constexpr int OFF_H1 = P * LD0, OFF_H2 = OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH, TOTAL = OFF_RED + 4 * P * 12;
+    static constexpr int OFF_H1 = P * LD0, OFF_H2 = OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH, TOTAL = OFF_RED + 16 * P * 12;
 };
 
-// f_theta for the tile's rows -> fout[P][9] in LDS (red area, wave 0 slot), before the output bias.
-// x rows must already be in X0 (cols 0..8, zero padded to 16).  rows >= nrows are clamped duplicates.
+struct TrunkPre {
+    WStages<4> stA;  // first-layer weights (stages 0,1)
+    f32x4 b0[4];     // first-layer bias fragments
+};
+
+// Entry sequence shared by every kernel that evaluates the trunk: request the first layer's weights and bias
+// (call BEFORE any prologue work so the latency overlaps it).
+template <int P>
+__device__ __forceinline__ void trunk_begin(const gp_scorenet &net, TrunkPre &pre) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncl[4] = {wave, wave + 4, wave + 8, wave + 12};
+    mfma_preload<4>(pre.stA, net.w_pose0, 1, HID / 16, ncl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre.b0[i] = *reinterpret_cast<const f32x4 *>(net.b_pose0 + ncl[i] * 16 + 4 * (lane >> 4));
+}
+
+// dense 256-wide layer of the trunk on pre-requested weights and bias: out = relu(X W^T + b) -> LDS.
+template <int PT>
+__device__ __forceinline__ void trunk_dense(WStages<4> &st, const f32x4 (&bias)[4], const float *Xs, int ld, const float *__restrict__ Wp, int K,
+                                            float *Ys, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc[4] = {wave, wave + 4, wave + 8, wave + 12};
+    f32x4 acc[4][PT];
+    mfma_run<4, PT>(st, Xs, ld, 0, Wp, gp_round16(K) / 16, HID / 16, nc, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = nc[i] * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            f32x4 v = acc[i][p] + bias[i];
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<f32x4 *>(Ys + (p * 16 + (lane & 15)) * ldo + ch) = v;
+        }
+    }
+}
+
+// epilogue operands of one head for this wave's four 16-channel chunks
+template <int PT>
+struct HeadOps {
+    f32x4 tv[4], w0[4], w1[4], w2[4], cv[4][PT];
+};
+
+template <int PT>
+__device__ __forceinline__ void head_ops_load(HeadOps<PT> &o, const gp_scorenet &net, const float *__restrict__ cvec,
+                                              const float *__restrict__ tvec, int h, const int (&nc)[4], const int (&cloud)[PT]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = nc[i] * 16 + 4 * (lane >> 4);  // 0..767
+        const int chh = ch - 256 * h;
+        o.tv[i] = *reinterpret_cast<const f32x4 *>(tvec + ch);
+        o.w0[i] = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 0) * HID + chh);
+        o.w1[i] = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 1) * HID + chh);
+        o.w2[i] = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 2) * HID + chh);
+#pragma unroll
+        for (int p = 0; p < PT; ++p) o.cv[i][p] = *reinterpret_cast<const f32x4 *>(cvec + (size_t)cloud[p] * HEADS + ch);
+    }
+}
+
+// f_theta (+ output bias) for the tile's rows -> H1[r*LDH + j], j < 9.
+// Preconditions: x rows in X0 (cols 0..8, zero padded to 16) + ONE __syncthreads(); trunk_begin() issued earlier.
+// rows >= nrows are clamped duplicates.
 template <int P>
 __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net, const float *__restrict__ cvec, const float *__restrict__ tvec,
-                                             int row0, int nrows, int kcand) {
+                                             int row0, int nrows, int kcand, TrunkPre &pre) {
     using L = TrunkLds<P>;
     constexpr int PT = P / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *X0 = lds, *H1 = lds + L::OFF_H1, *H2 = lds + L::OFF_H2, *red = lds + L::OFF_RED;
-    dense_to_lds<4, PT, 4, true>(X0, L::LD0, net.w_pose0, net.b_pose0, POSE, HID, H1, L::LDH);
-    __syncthreads();
-    dense_to_lds<4, PT, 4, true>(H1, L::LDH, net.w_pose2, net.b_pose2, HID, HID, H2, L::LDH);
-    __syncthreads();
-    // stacked head layer (256 -> 768) with the 256 -> 3 output layers folded into the epilogue
+    const int ncl[4] = {wave, wave + 4, wave + 8, wave + 12};
+    int nch[3][4];
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nch[h][i] = 16 * h + wave + 4 * i;  // head h owns n-chunks [16h, 16h+16)
     int cloud[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
@@ -37,55 +101,67 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         if (r >= nrows) r = nrows - 1;
         cloud[p] = r / kcand;
     }
-#pragma unroll 1
+    GP_T(2);
+    // ---- layer 1 (9 -> 256); layer 2's first weight stages and bias are requested before it runs
+    WStages<4> stB;
+    f32x4 b2[4];
+    mfma_preload<4>(stB, net.w_pose2, HID / 16, HID / 16, ncl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b2[i] = *reinterpret_cast<const f32x4 *>(net.b_pose2 + ncl[i] * 16 + 4 * (lane >> 4));
+    trunk_dense<PT>(pre.stA, pre.b0, X0, L::LD0, net.w_pose0, POSE, H1, L::LDH);
+    __syncthreads();
+    GP_T(3);
+    // ---- layer 2 (256 -> 256); head 0's weights (and, small tile, its epilogue operands) requested before it runs
+    WStages<4> stH[2];
+    mfma_preload<4>(stH[0], net.w_headx, HID / 16, HEADS / 16, nch[0]);
+    trunk_dense<PT>(stB, b2, H1, L::LDH, net.w_pose2, HID, H2, L::LDH);
+    GP_T(4);
+    __syncthreads();
+    GP_T(5);
+    // ---- stacked head layer (256 -> 768) with the 256 -> 3 output layers folded into the epilogue
+#pragma unroll
     for (int h = 0; h < 3; ++h) {
-        // head h owns n-chunks [16h, 16h+16); wave w takes chunks 16h + w + 4i, i = 0..3
+        f32x4 acc[4][PT];
+        GP_T(6 + 3 * h);
+        // next head's first weight stages are requested before this head runs (hides the cold start).  The epilogue
+        // operands are NOT hoisted above the MFMA loop: measured slower (their ~20 KB/wave of broadcast loads queue
+        // in front of the loop's counted weight prefetches).
+        if (h < 2) mfma_preload<4>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
+        mfma_run<4, PT>(stH[h & 1], H2, L::LDH, 0, net.w_headx, HID / 16, HEADS / 16, nch[h], acc);
+        GP_T(7 + 3 * h);
+        HeadOps<PT> o;
+        head_ops_load<PT>(o, net, cvec, tvec, h, nch[h], cloud);
         float part[PT][3];  // [p-chunk][component], this wave's n-chunks of head h
 #pragma unroll
         for (int p = 0; p < PT; ++p) part[p][0] = part[p][1] = part[p][2] = 0.f;
-        int nc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nc[i] = 16 * h + wave + 4 * i;
-        f32x4 acc[4][PT];
-        mfma_tile<4, PT>(H2, L::LDH, 0, net.w_headx, HID / 16, nc, acc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ch = nc[i] * 16 + 4 * (lane >> 4);  // 0..767
-            const f32x4 tv = *reinterpret_cast<const f32x4 *>(tvec + ch);
-            const int chh = ch - 256 * h;
-            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 0) * HID + chh);
-            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 1) * HID + chh);
-            const f32x4 w2 = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 2) * HID + chh);
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
-                const f32x4 cv = *reinterpret_cast<const f32x4 *>(cvec + (size_t)cloud[p] * HEADS + ch);
-                f32x4 v = acc[i][p] + cv + tv;
+                f32x4 v = acc[i][p] + o.cv[i][p] + o.tv[i];
                 v.x = fmaxf(v.x, 0.f);
                 v.y = fmaxf(v.y, 0.f);
                 v.z = fmaxf(v.z, 0.f);
                 v.w = fmaxf(v.w, 0.f);
-                part[p][0] += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
-                part[p][1] += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
-                part[p][2] += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+                part[p][0] += v.x * o.w0[i].x + v.y * o.w0[i].y + v.z * o.w0[i].z + v.w * o.w0[i].w;
+                part[p][1] += v.x * o.w1[i].x + v.y * o.w1[i].y + v.z * o.w1[i].z + v.w * o.w1[i].w;
+                part[p][2] += v.x * o.w2[i].x + v.y * o.w2[i].y + v.z * o.w2[i].z + v.w * o.w2[i].w;
             }
         }
-        // reduce over the 4 lane groups (channels) of the wave; waves are combined below through LDS (fixed order)
+        // every lane parks its partial sums; the 4 channel groups x 4 waves are combined below in a fixed order
 #pragma unroll
         for (int p = 0; p < PT; ++p)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float v = part[p][c];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (lane < 16) red[(wave * P + p * 16 + lane) * 12 + 3 * h + c] = v;
-            }
+            for (int c = 0; c < 3; ++c) red[((wave * 4 + (lane >> 4)) * P + p * 16 + (lane & 15)) * 12 + 3 * h + c] = part[p][c];
+        GP_T(8 + 3 * h);
     }
     __syncthreads();
     for (int e = tid; e < P * POSE; e += 256) {
         const int r = e / POSE, j = e - r * POSE;
-        const float v = ((red[(0 * P + r) * 12 + j] + red[(1 * P + r) * 12 + j]) + red[(2 * P + r) * 12 + j]) + red[(3 * P + r) * 12 + j];
-        // park the result in H1 (free now): H1[r*LDH + j]
-        H1[r * L::LDH + j] = v + net.b_out[j];
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[(q * P + r) * 12 + j];
+        H1[r * L::LDH + j] = v + net.b_out[j];  // parked in H1 (free now)
     }
     __syncthreads();
 }

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void cloud_embed_kernel(int nb, gp_scorenet ne
     const int ncb = blockIdx.y * 16 + wave * 4;
     int nc[4] = {ncb, ncb + 1, ncb + 2, ncb + 3};
     f32x4 acc[4][1];
-    mfma_tile<4, 1>(lds, LD, 0, net.w_headp, K / 16, nc, acc);
+    mfma_tile<4, 1>(lds, LD, 0, net.w_headp, K / 16, HEADS / 16, nc, acc);
     const int row = r0 + (lane & 15);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256, 2) void score_eval_kernel(int nrows, int kcand
     using L = TrunkLds<P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int row0 = blockIdx.x * P, tid = threadIdx.x;
+    TrunkPre pre;
+    trunk_begin<P>(net, pre);
     load_x_tile<P>(lds, x, row0, nrows);
     __syncthreads();
-    trunk_ftheta<P>(lds, net, cvec, tvec, row0, nrows, kcand);
+    trunk_ftheta<P>(lds, net, cvec, tvec, row0, nrows, kcand, pre);
     const float sigma = *sigma_dev;
     const float *F = lds + L::OFF_H1;
     if (mode == 0) {
@@ -122,36 +124,45 @@ __global__ __launch_bounds__(256, 2) void pc_step_kernel(PcArgs a, gp_scorenet n
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_gn;
     const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
+    if (i < a.nsteps) GP_T(0);
+    TrunkPre pre;
+    if (i < a.nsteps) trunk_begin<P>(net, pre);
     if (i > 0) {
-        // batch-mean gradient norm of step i-1: fixed-order sum of the per-block partials (deterministic)
-        if (tid < 64) {
-            float s = 0.f;
-            const float *pp = a.partials + (size_t)(i - 1) * a.nblocks;
-            for (int q = tid; q < a.nblocks; q += 64) s += pp[q];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-            if (tid == 0) s_gn = s / (float)a.nrows;
-        }
-        __syncthreads();
+        // (1) row threads request their operands first; (2) meanwhile the last wave reduces the per-block partial sums
+        // of step i-1 into the batch-mean gradient norm (fixed order: deterministic); (3) one barrier, then the update.
+        const bool live = row0 + tid < a.nrows;
+        const int r = live ? row0 + tid : a.nrows - 1;  // rows past the end: clamped duplicates (computed, never stored)
+        float xv[9], gr[9], zz1[9], zz2[9], g = 0.f, dt = 0.f, sqdt = 0.f, cen[3] = {0.f, 0.f, 0.f};
         if (tid < P) {
-            // rows past the end are clamped duplicates of the last row (computed, never stored)
-            const bool live = row0 + tid < a.nrows;
-            const int r = live ? row0 + tid : a.nrows - 1;
             const float *sc = a.sched + (size_t)(i - 1) * 4;
-            const float g = sc[1], dt = sc[2], sqdt = sc[3];
-            float xv[9], gr[9];
+            g = sc[1], dt = sc[2], sqdt = sc[3];
+            const float *z1 = a.z_lang + ((size_t)(i - 1) * a.nrows + r) * 9;
+            const float *z2 = a.z_pred + ((size_t)(i - 1) * a.nrows + r) * 9;
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 xv[j] = a.x[(size_t)r * 9 + j];
                 gr[j] = a.score[(size_t)r * 9 + j];
+                zz1[j] = z1[j];
+                zz2[j] = z2[j];
             }
-            const float *z1 = a.z_lang + ((size_t)(i - 1) * a.nrows + r) * 9;
-            const float *z2 = a.z_pred + ((size_t)(i - 1) * a.nrows + r) * 9;
+            const float *cp = a.centre + (size_t)(r / a.kcand) * 3;
+            cen[0] = cp[0], cen[1] = cp[1], cen[2] = cp[2];
+        }
+        if (tid >= 192) {
+            float s = 0.f;
+            const float *pp = a.partials + (size_t)(i - 1) * a.nblocks;
+            for (int q = tid - 192; q < a.nblocks; q += 64) s += pp[q];
+            s = wave_sum_f32(s);
+            if (tid == 192) s_gn = s / (float)a.nrows;
+        }
+        __syncthreads();
+        if (i < a.nsteps) GP_T(20);
+        if (tid < P) {
             const float q = 0.48f / s_gn;  // snr * sqrt(pose_dim) = 0.16 * 3
             const float lstep = 2.0f * (q * q);
             const float ns = sqrtf(2.0f * lstep);
 #pragma unroll
-            for (int j = 0; j < 9; ++j) xv[j] = (xv[j] + lstep * gr[j]) + ns * z1[j];
+            for (int j = 0; j < 9; ++j) xv[j] = (xv[j] + lstep * gr[j]) + ns * zz1[j];
             float n1 = sqrtf(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2]);
             float n2 = sqrtf(xv[3] * xv[3] + xv[4] * xv[4] + xv[5] * xv[5]);
 #pragma unroll
@@ -165,10 +176,9 @@ __global__ __launch_bounds__(256, 2) void pc_step_kernel(PcArgs a, gp_scorenet n
             for (int j = 0; j < 9; ++j) {
                 const float drift = 0.f - g2 * gr[j];  // sign as written in the reference (samplers.py:147)
                 mx[j] = xv[j] + drift * dt;
-                xv[j] = mx[j] + (g * sqdt) * z2[j];
+                xv[j] = mx[j] + (g * sqdt) * zz2[j];
             }
             normalize_rot6(xv);
-            const float *cen = a.centre + (size_t)(r / a.kcand) * 3;
             if (live) {
                 if (a.traj) {
                     float *tr = a.traj + ((size_t)(i - 1) * a.nrows + r) * 9;
@@ -199,7 +209,9 @@ __global__ __launch_bounds__(256, 2) void pc_step_kernel(PcArgs a, gp_scorenet n
         load_x_tile<P>(lds, a.x, row0, a.nrows);
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand);
+    GP_T(1);
+    trunk_ftheta<P>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre);
+    GP_T(16);
     const float sigma = a.sched[(size_t)i * 4 + 0];
     float *F = lds + L::OFF_H1;
     for (int e = tid; e < P * POSE; e += 256) {
@@ -223,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void pc_step_kernel(PcArgs a, gp_scorenet n
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
         if (tid == 0) a.partials[(size_t)i * a.nblocks + blockIdx.x] = s;
     }
+    GP_T(17);
 }
 
 }  // namespace
