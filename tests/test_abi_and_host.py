@@ -1,0 +1,186 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/genpose_hip.h declares; host-side logic
+(weight packing, BN folding, schedules, rotations, runner glue, config, error behaviour without a device)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import genpose_oracle as go
+from oracle import rot as orot
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "genpose_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(gp_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from genpose_amd import _lib, build
+    build.build()
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/genpose_hip.h but not exported"
+    for s in _lib.SIGNATURES:
+        assert s in syms or s == "gp_debug_timestamps", f"{s} bound in _lib.py but not declared in the header"
+    assert _lib.lib().gp_version() == 1
+
+
+def test_pointnet2_cuda_surface_matches_reference_names():
+    """The nine pybind names of pointnet2_api.cpp:10-24."""
+    import genpose_amd.pointnet2_cuda as m
+    names = ["ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper", "gather_points_wrapper",
+             "gather_points_grad_wrapper", "furthest_point_sampling_wrapper", "three_nn_wrapper", "three_interpolate_wrapper",
+             "three_interpolate_grad_wrapper"]
+    for n in names:
+        assert callable(getattr(m, n))
+    x = torch.zeros(1, 8, 3)
+    with pytest.raises(RuntimeError):  # CPU tensors are rejected like CHECK_CUDA (ball_query.cpp:12)
+        m.ball_query_wrapper(1, 8, 8, 0.1, 4, x, x, torch.zeros(1, 8, 4, dtype=torch.int32))
+
+
+def test_no_cpu_fallback():
+    from genpose_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.GenposeHipError):
+        _lib.check_device()
+    from genpose_amd.encoder import Pointnet2EncoderHIP
+    enc = Pointnet2EncoderHIP(go.make_state_dict(0, "score"), "cpu")
+    with pytest.raises(_lib.GenposeHipError):
+        enc.forward(torch.zeros(1, 1024, 3))
+
+
+def test_pack_weight_layout():
+    from genpose_amd.weights import pack_weight
+    W = torch.arange(20 * 37, dtype=torch.float32).reshape(20, 37)
+    p = pack_weight(W)
+    NC, KG = 2, 3
+    assert p.numel() == NC * KG * 256
+    p = p.reshape(KG, NC, 64, 4)
+    for kg in range(KG):
+        for nc in range(NC):
+            for lane in (0, 5, 17, 63):
+                for jj in range(4):
+                    n, k = nc * 16 + (lane & 15), kg * 16 + 4 * (lane >> 4) + jj
+                    exp = W[n, k].item() if (n < 20 and k < 37) else 0.0
+                    assert p[kg, nc, lane, jj].item() == exp
+
+
+def test_bn_folding_equals_conv_bn():
+    """weights.SAScale folds eval-BatchNorm into the 1x1 conv and moves [dx,dy,dz] behind the features."""
+    sd = go.make_state_dict(0, "score")
+    prefix = "pts_encoder.SA_modules.1.mlps.0."
+    x = torch.randn(2, 99, 5, 7)
+    ref = go._shared_mlp(sd, prefix, x)
+    cur = torch.cat([x[:, 3:], x[:, :3]], dim=1)  # kernel input order: features first, then dx,dy,dz
+    for l in range(3):
+        p = f"{prefix}layer{l}."
+        W = sd[p + "conv.weight"].double().reshape(sd[p + "conv.weight"].shape[0], -1)
+        scale = sd[p + "bn.bn.weight"].double() / torch.sqrt(sd[p + "bn.bn.running_var"].double() + 1e-5)
+        Wf = W * scale[:, None]
+        bf = sd[p + "bn.bn.bias"].double() - sd[p + "bn.bn.running_mean"].double() * scale
+        if l == 0:
+            Wf = torch.cat([Wf[:, 3:], Wf[:, :3]], dim=1)
+        cur = torch.relu(torch.einsum("oc,bchw->bohw", Wf.float(), cur) + bf.float()[None, :, None, None])
+    np.testing.assert_allclose(cur.numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    from genpose_amd.weights import EncoderWeights
+    ew = EncoderWeights(sd, "cpu")
+    assert ew.out_dim == 1024 and [s.couts for s in ew.levels[2]] == [[128, 196, 256], [128, 196, 256]]
+
+
+def test_scorenet_weight_block_shapes():
+    from genpose_amd.weights import ScoreNetWeights
+    w = ScoreNetWeights(go.make_state_dict(0, "energy"), "cpu")
+    t = w.tensors
+    assert t["w_headp"].numel() == 48 * 64 * 256 and t["w_headx"].numel() == 48 * 16 * 256
+    assert t["w_t1"].shape == (128, 128) and t["w_headt"].shape == (128, 768) and t["w_out"].shape == (9, 256)
+    bad = {k: v for k, v in go.make_state_dict(0, "score").items() if "fusion_tail_trans" not in k}
+    with pytest.raises(KeyError):
+        ScoreNetWeights(bad, "cpu")
+
+
+def test_pc_schedule_matches_reference_expressions():
+    from genpose_amd.samplers import pc_schedule
+    ts, sched = pc_schedule(100)
+    ref_ts = torch.linspace(1.0, 1e-5, 100)
+    assert torch.equal(ts, ref_ts)
+    bt = torch.ones(7, 1) * ref_ts[13]
+    assert torch.allclose(sched[13, 0], go.ve_sigma(bt)[0, 0], rtol=1e-6)
+    assert torch.allclose(sched[13, 1], go.ve_diffusion(bt)[0, 0], rtol=1e-6)
+    assert sched[13, 2] == ref_ts[0] - ref_ts[1] and sched[13, 3] == torch.sqrt(ref_ts[0] - ref_ts[1])
+
+
+def test_rotation_helpers_match_oracle():
+    from genpose_amd import rotation
+    g = torch.Generator().manual_seed(2)
+    r6 = torch.randn(50, 6, generator=g, dtype=torch.float64)
+    R = rotation.get_rot_matrix(r6)
+    np.testing.assert_allclose(R.numpy(), go.get_rot_matrix(r6).numpy(), atol=1e-14)
+    np.testing.assert_allclose(rotation.normalize_rotation(r6).numpy(), go.normalize_rotation(r6).numpy(), atol=1e-14)
+    q = rotation.matrix_to_quaternion(R)
+    np.testing.assert_allclose(q.numpy(), orot.matrix_to_quaternion(R).numpy(), atol=1e-14)
+    np.testing.assert_allclose(rotation.quaternion_to_matrix(q).numpy(), R.numpy(), atol=1e-12)
+    Q = q.reshape(5, 10, 4).float()
+    a, b = rotation.average_quaternion_batch(Q), go.average_quaternion_batch(Q)
+    np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-5)
+    pose = torch.cat([r6, torch.randn(50, 3, generator=g, dtype=torch.float64)], dim=1)
+    np.testing.assert_allclose(rotation.pose9_to_RT(pose).numpy(), go.pose9_to_RT(pose), atol=1e-14)
+
+
+def test_add_noise_to_RT_golden(golden):
+    """runner.add_noise_to_RT against the reference's own output (logged draws + resulting init_x in G9 frame 0)."""
+    from genpose_amd.runner import add_noise_to_RT
+    g = golden("g9_track.npz")
+    draws = [torch.from_numpy(g[f"f0_noise_draw{d}"]) for d in range(4)]
+    RT = add_noise_to_RT(torch.from_numpy(g["gt_RT"]), draws=draws)
+    cen = torch.from_numpy(g["frames"][0]).mean(dim=1)
+    init_x = torch.cat([RT[:, :3, 0], RT[:, :3, 1], RT[:, :3, 3] - cen], dim=-1)
+    np.testing.assert_allclose(init_x.numpy(), g["f0_init_x"], atol=1e-6)
+
+
+def test_config_and_agent_errors():
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    cfg = get_config(device="cpu", sampler_mode=["pc"], sampling_steps=5)
+    agent = PoseNet(cfg)
+    with pytest.raises(ValueError):  # posenet_agent.py:160
+        agent.load_ckpt(model_dir="/nonexistent/ckpt_genpose.pth", model_path=True, load_model_only=True)
+    with pytest.raises(NotImplementedError):  # posenet.py:178-179
+        agent.net({"pts": torch.zeros(1, 8, 3)}, mode="bogus")
+    with pytest.raises(RuntimeError):
+        agent.net({"pts": torch.zeros(1, 1024, 3)}, mode="pts_feature")  # no weights loaded
+    with pytest.raises(ValueError):
+        get_config(nonexistent_flag=1)
+    with pytest.raises(NotImplementedError):
+        PoseNet(get_config(device="cpu", sde_mode="vp"))
+    with pytest.raises(NotImplementedError):
+        PoseNet(get_config(device="cpu", pts_encoder="pointnet"))
+
+
+def test_load_ckpt_accepts_reference_checkpoint_layout(tmp_path):
+    """A torch.save'd dict with 'model_state_dict' under the reference key schema loads (weights packed on the CPU)."""
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    path = tmp_path / "ckpt_genpose.pth"
+    torch.save({"clock": {}, "model_state_dict": go.make_state_dict(3, "score"), "optimizer_state_dict": {}, "scheduler_state_dict": {}}, path)
+    agent = PoseNet(get_config(device="cpu"))
+    agent.load_ckpt(model_dir=str(path), model_path=True, load_model_only=True)
+    assert agent.net.pts_encoder.out_dim == 1024
+
+
+def test_synth_is_deterministic_and_real275_shaped():
+    from genpose_amd import synth
+    a, b = synth.make_batch(6, start=3), synth.make_batch(6, start=3)
+    assert a.shape == (6, 1024, 3) and a.dtype == np.float32 and np.array_equal(a, b)
+    assert 0.3 < a[..., 2].min() and a[..., 2].max() < 1.6  # metres in front of the camera
+    assert np.allclose(a[..., 2] * 1000, np.round(a[..., 2] * 1000), atol=1e-3)  # 1 mm depth quantisation
+    g = synth.golden_clouds()
+    assert len(np.unique(g[2], axis=0)) < 1024  # tiled duplicates present (FPS ties)
