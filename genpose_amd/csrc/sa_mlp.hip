@@ -186,7 +186,10 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
     }
     // 32-row tiles keep 2-3 workgroups per CU resident (gather of one overlaps the MFMA phase of another); measured
     // faster than 64-row tiles on every level of the light config.  ns = 64 needs 64 rows (one wave owns a neighbourhood).
-    if (groupall || (ns <= 32 && forced != 64)) return launch<32>(a, b, st);
+    // Narrow levels (all widths <= 64: SA level 0) are overhead-bound, not MFMA-bound: 64-row tiles halve the per-tile
+    // fixed cost (measured 274 vs 382 us at B = 64).
+    const bool narrow = c1 <= 64 && c2 <= 64 && c3 <= 64;
+    if (groupall || (ns <= 32 && forced != 64 && !(narrow && forced != 32))) return launch<32>(a, b, st);
     if (lds_bytes(64, a) <= 150 * 1024) return launch<64>(a, b, st);
     return GP_EINVAL;
 }

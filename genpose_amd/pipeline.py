@@ -1,0 +1,92 @@
+"""Two-stream software pipeline over batches: the encoder of batch i+1 runs on one HIP stream while the T-step sampler
+hipGraph of batch i runs on another.  The sampler's launches occupy at most ceil(R/16) workgroups (200 of 256 CUs at the
+bench configuration) and stall on every step boundary; the encoder's thousands of workgroups fill those holes.  Batches
+are independent, so this changes throughput only - every batch's result is identical to the sequential
+`PoseNet.pred_func` (asserted in tests/test_gpu_pipeline.py).
+"""
+import torch
+
+from . import _lib
+from .samplers import PCSampler
+from .sde import SIGMA_MAX
+
+
+class PipelinedPCPredictor:
+    """pred_func(encoder + PC sampler) for a stream of equally-shaped batches.
+
+    score_agent : genpose_amd.posenet_agent.PoseNet (weights loaded, sampler_mode ['pc'])
+    """
+
+    def __init__(self, score_agent, B, K, num_steps, depth=2, sampler_streams=1):
+        _lib.check_device()
+        self.net = score_agent.net
+        self.net._need_weights()
+        self.B, self.K, self.n, self.depth = B, K, num_steps, depth
+        self.dev = self.net.device
+        self.s_enc = torch.cuda.Stream(self.dev)
+        # (sampler_streams > 1 puts several sampler chains in flight; measured SLOWER at the bench configuration:
+        #  13.1 k vs 14.2 k poses/s - the chains contend for the same MFMA pipes and each step boundary gets longer)
+        self.s_smp = [torch.cuda.Stream(self.dev) for _ in range(sampler_streams)]
+        self.smp = [PCSampler(self.net.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False)
+                    for _ in range(sampler_streams)]
+        self.timing = False
+        self.smp_events = []
+        R = B * K
+        self.cvec = [torch.empty(B, 768, device=self.dev) for _ in range(depth)]
+        self.centre = [torch.empty(B, 3, device=self.dev) for _ in range(depth)]
+        self.x0 = [torch.empty(R, 9, device=self.dev) for _ in range(depth)]
+        self.ev_enc = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_free = [torch.cuda.Event() for _ in range(depth)]
+        self.prior_host = [torch.empty(R, 9).pin_memory() for _ in range(depth)]
+        for e in self.ev_free:
+            e.record(self.s_smp[0])
+
+    def run(self, batches, prior_noise=None, noise=None, out=None):
+        """batches: sequence of device tensors [B,1024,3].  prior_noise / noise: optional per-batch explicit draws (tests).
+        Returns a list of pred_pose [B,K,9] float32 tensors (one per batch; written into `out[i]` when given)."""
+        results = []
+        cur = torch.cuda.current_stream(self.dev)
+        self.s_enc.wait_stream(cur)
+        for st in self.s_smp:
+            st.wait_stream(cur)
+        for i, pts in enumerate(batches):
+            slot = i % self.depth
+            # ---- encoder stage (stream E): features -> per-cloud embedding, prior -> device
+            with torch.cuda.stream(self.s_enc):
+                self.s_enc.wait_event(self.ev_free[slot])  # the sampler has consumed this slot's previous contents
+                feat = self.net.pts_encoder(pts)
+                cv = self.net.pose_score_net.cloud_embed(feat)
+                self.cvec[slot].copy_(cv)
+                self.centre[slot].copy_(pts.mean(dim=1))
+                if prior_noise is None:
+                    torch.randn(self.prior_host[slot].shape, out=self.prior_host[slot])  # CPU generator, as sde.py:28
+                    self.x0[slot].copy_(self.prior_host[slot], non_blocking=True)
+                else:
+                    self.x0[slot].copy_(prior_noise[i])
+                self.x0[slot].mul_(SIGMA_MAX)  # prior std at T = 1 (cond_pc_sampler always starts from T = 1)
+                self.ev_enc[slot].record(self.s_enc)
+            # ---- sampler stage (stream S): the whole T-step loop as one graph replay
+            j = i % len(self.s_smp)
+            with torch.cuda.stream(self.s_smp[j]):
+                self.s_smp[j].wait_event(self.ev_enc[slot])
+                z1, z2 = noise[i] if noise is not None else (None, None)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.timing else None
+                _, mean_x = self.smp[j].run(self.cvec[slot], self.centre[slot], self.x0[slot], z1, z2, slot_free_event=self.ev_free[slot],
+                                            graph_events=ev)
+                res = out[i] if out is not None else torch.empty(self.B, self.K, 9, device=self.dev)
+                res.copy_(mean_x.reshape(self.B, self.K, 9))
+                results.append(res)
+                if ev is not None:
+                    self.smp_events.append(ev)
+        for st in self.s_smp:
+            cur.wait_stream(st)
+        cur.wait_stream(self.s_enc)
+        return results
+
+    def sampler_launch_seconds(self):
+        """Average duration of one pc_step launch inside the pipelined region (HIP events around every graph replay on
+        the sampler streams; call after a synchronize)."""
+        if not self.smp_events:
+            return None
+        tot = sum(a.elapsed_time(b) for a, b in self.smp_events) * 1e-3
+        return tot / (len(self.smp_events) * (self.n + 1))

@@ -29,23 +29,27 @@ class SingleFrameRunner:
         self.score_agent, self.energy_agent = score_agent, energy_agent
         self.repeat_num, self.T0, self.batch_size, self.ratio = repeat_num, T0, batch_size, ratio
 
-    def infer(self, clouds, device="cuda"):
-        """clouds: array-like [n,1024,3].  Returns dict of numpy arrays (+ 'pred_pose' [n,K,9])."""
-        clouds = torch.as_tensor(np.asarray(clouds), dtype=torch.float32)
+    def infer_tensors(self, clouds):
+        """clouds: device tensor [n,1024,3] -> dict of device tensors with leading dim n (usable under ShardedInference)."""
         n = clouds.shape[0]
         out = {"pred_pose": [], "multi_hypothesis_pred_RTs": [], "energy": [], "sorted_RTs": [], "average_sRT": []}
         for s in range(0, n, self.batch_size):  # evaluation_single.py:380-382 batch slicing
-            sample = make_batch_sample(clouds[s:s + self.batch_size].to(device))
+            sample = make_batch_sample(clouds[s:s + self.batch_size])
             pred = self.score_agent.pred_func(data=sample, repeat_num=self.repeat_num, save_path=None, T0=self.T0)
-            out["pred_pose"].append(pred.cpu().numpy())
-            out["multi_hypothesis_pred_RTs"].append(rotation.pose9_to_RT(pred).cpu().numpy())
+            out["pred_pose"].append(pred)
+            out["multi_hypothesis_pred_RTs"].append(rotation.pose9_to_RT(pred))
             if self.energy_agent is not None:
                 energy = self.energy_agent.get_energy(data=sample, pose_samples=pred, T=1e-5)  # evaluation_single.py:339-343
                 r = reward.rank_aggregate(pred, energy, ratio=self.ratio)
-                out["energy"].append(energy.cpu().numpy())
-                out["sorted_RTs"].append(rotation.pose9_to_RT(r["sorted_poses"]).cpu().numpy())
-                out["average_sRT"].append(rotation.quat_trans_to_RT(r["avg_pose"].double()).cpu().numpy())
-        return {k: np.concatenate(v, axis=0) for k, v in out.items() if v}
+                out["energy"].append(energy)
+                out["sorted_RTs"].append(rotation.pose9_to_RT(r["sorted_poses"]))
+                out["average_sRT"].append(rotation.quat_trans_to_RT(r["avg_pose"].double()))
+        return {k: torch.cat(v, dim=0) for k, v in out.items() if v}
+
+    def infer(self, clouds, device="cuda"):
+        """clouds: array-like [n,1024,3].  Returns dict of numpy arrays (+ 'pred_pose' [n,K,9])."""
+        clouds = torch.as_tensor(np.asarray(clouds), dtype=torch.float32).to(device)
+        return {k: v.cpu().numpy() for k, v in self.infer_tensors(clouds).items()}
 
 
 # ------------------------------------------------------------------ tracking

@@ -52,12 +52,15 @@ class PCSampler:
                       ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
                       ptr(self.traj), st)
 
-    def run(self, cvec, centre, init_x, z_langevin=None, z_predictor=None):
+    def run(self, cvec, centre, init_x, z_langevin=None, z_predictor=None, slot_free_event=None, graph_events=None):
         """cvec [B,768], centre [B,3], init_x [R,9]; noise [n,R,9] (drawn on the device generator if None).
-        Returns (xs [R,n,9] or None, mean_x [R,9]) float32, like cond_pc_sampler."""
+        Returns (xs [R,n,9] or None, mean_x [R,9]) float32, like cond_pc_sampler.
+        slot_free_event: recorded once the inputs have been copied into the sampler's own buffers (pipelining)."""
         self.cvec.copy_(cvec)
         self.centre.copy_(centre)
         self.x.copy_(init_x)
+        if slot_free_event is not None:
+            slot_free_event.record(torch.cuda.current_stream())
         if z_langevin is None:
             self.z1.normal_()
             self.z2.normal_()
@@ -76,7 +79,11 @@ class PCSampler:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
                     self._launch_all()
+            if graph_events is not None:
+                graph_events[0].record(torch.cuda.current_stream())
             self.graph.replay()
+            if graph_events is not None:
+                graph_events[1].record(torch.cuda.current_stream())
         xs = self.traj.permute(1, 0, 2) if self.traj is not None else None
         return xs, self.mean_x
 
