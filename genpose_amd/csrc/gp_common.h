@@ -99,8 +99,10 @@ __device__ __forceinline__ void mfma_run(WStages<NV> &st, const float *Xs, int l
         for (int d = 0; d < 3; ++d) {
             const int nxt = (kg + d + 2 < KG) ? kg + d + 2 : KG - 1;
             const int e = (d + 2) % 3;
+#ifndef GP_EXP_NOWLOAD
 #pragma unroll
             for (int i = 0; i < NV; ++i) st.w[e][i] = wp[i][(size_t)nxt * kstride];
+#endif
 #pragma unroll
             for (int p = 0; p < PT; ++p) xq[e][p] = *reinterpret_cast<const f32x4 *>(xrow[p] + nxt * 16);
             __builtin_amdgcn_sched_barrier(0);
