@@ -138,6 +138,143 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SAArgs a) {
     layer3_max<P / 16, 4>(a, A, lda, c2p, row0, b);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Hoisted first layer (exact algebra):  W1.[feat_j ; xyz_j - c] = W1f.feat_j + W1x.(xyz_j - c)
+// The feature half depends on the SOURCE point only, so it is computed once per point (n rows) by point_linear_kernel
+// instead of once per (centre, sample) pair (np*ns = 8..16 n rows); the xyz half is three FMAs per channel, applied while
+// the neighbourhood is gathered.  Saves ~27 % of the encoder's MFMA work, halves the gather bytes and drops the K0-wide
+// LDS buffer.  (The reference materialises the grouped tensor and convolves all of it, pointnet2_utils.py:246-258.)
+
+// Z[row, 0:N] = X[row, 0:K] . W^T   (no bias, no activation), rows = B*n points, 64 rows per workgroup
+__global__ __launch_bounds__(256) void point_linear_kernel(int M, int K, int N, const float *__restrict__ X, const float *__restrict__ Wp,
+                                                           float *__restrict__ Z) {
+    constexpr int P = 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * P, Kp = gp_round16(K), ld = Kp + GP_LD_PAD;
+    const int q4 = K >> 2;
+    for (int e = tid; e < P * q4; e += 256) {
+        const int r = e / q4, q = e - r * q4;
+        int g = row0 + r;
+        if (g >= M) g = M - 1;
+        *reinterpret_cast<f32x4 *>(lds + r * ld + 4 * q) = *reinterpret_cast<const f32x4 *>(X + (size_t)g * K + 4 * q);
+    }
+    if (Kp > K)
+        for (int e = tid; e < P * (Kp - K); e += 256) lds[(e / (Kp - K)) * ld + K + e % (Kp - K)] = 0.f;
+    __syncthreads();
+    // each wave owns 16 rows and sweeps all channel chunks
+    const int KG = Kp / 16, NC = gp_round16(N) / 16;
+    for (int ncb = 0; ncb < NC; ncb += 4) {
+        int nc[4], nv = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            nc[i] = ncb + i;
+            nv += nc[i] < NC;
+        }
+        f32x4 acc[4][1];
+        mfma_tile_n<1>(nv, lds, ld, wave, Wp, KG, NC, nc, acc);
+        const int row = row0 + wave * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= nv) break;
+            const int ch = nc[i] * 16 + 4 * (lane >> 4);
+            if (row < M && ch < N) *reinterpret_cast<f32x4 *>(Z + (size_t)row * N + ch) = acc[i][0];
+        }
+    }
+}
+
+struct SAPreArgs {
+    int n, np, ns, c1, c2, c3, zstride, zoff;
+    const float *xyz, *new_xyz, *z;  // z [b, n, zstride] or null (level 0: no input features)
+    const int32_t *idx;
+    const float *wxyz, *b1;          // wxyz [c1p][4] = (wx, wy, wz, 0) per channel; b1 [c1p]
+    const float *w2, *b2, *w3, *b3;
+    float *out;
+    int cout_total, cout_off;
+};
+
+template <int P>
+__global__ __launch_bounds__(256) void sa_pre_mlp_kernel(SAPreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, row0 = blockIdx.x * P;
+    const int c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
+    const int lda = c2p + GP_LD_PAD, ldb = c1p + GP_LD_PAD;
+    float *A = lds, *Bf = lds + P * lda;
+    float *dxyz = Bf + P * ldb;            // [P][4]
+    int *src = reinterpret_cast<int *>(dxyz + P * 4);  // [P] source point of every row
+    const int nrows = a.np * a.ns;
+    const float *xyz = a.xyz + (size_t)b * a.n * 3;
+    for (int r = tid; r < P; r += 256) {
+        int g = row0 + r;
+        if (g >= nrows) g = nrows - 1;
+        const int c = g / a.ns;
+        const int j = a.idx[((size_t)b * a.np) * a.ns + g];
+        const float *cp = a.new_xyz + ((size_t)b * a.np + c) * 3;
+        dxyz[r * 4 + 0] = xyz[j * 3 + 0] - cp[0];  // grouped_xyz -= new_xyz (pointnet2_utils.py:253)
+        dxyz[r * 4 + 1] = xyz[j * 3 + 1] - cp[1];
+        dxyz[r * 4 + 2] = xyz[j * 3 + 2] - cp[2];
+        dxyz[r * 4 + 3] = 0.f;
+        src[r] = j;
+    }
+    __syncthreads();
+    // ---- layer 1 while gathering: h1 = relu(Z[j] + wx*dx + wy*dy + wz*dz + b1)
+    {
+        const int q4 = c1p >> 2;
+        const float *zb = a.z ? a.z + (size_t)b * a.n * a.zstride + a.zoff : nullptr;
+        for (int e = tid; e < P * q4; e += 256) {
+            const int r = e / q4, q = e - r * q4;
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(dxyz + r * 4);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(a.b1 + 4 * q);
+            if (zb && 4 * q < a.c1) v += *reinterpret_cast<const f32x4 *>(zb + (size_t)src[r] * a.zstride + 4 * q);
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(a.wxyz + (4 * q + 0) * 4);
+            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(a.wxyz + (4 * q + 1) * 4);
+            const f32x4 w2 = *reinterpret_cast<const f32x4 *>(a.wxyz + (4 * q + 2) * 4);
+            const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.wxyz + (4 * q + 3) * 4);
+            v.x += w0.x * d.x + w0.y * d.y + w0.z * d.z;
+            v.y += w1.x * d.x + w1.y * d.y + w1.z * d.z;
+            v.z += w2.x * d.x + w2.y * d.y + w2.z * d.z;
+            v.w += w3.x * d.x + w3.y * d.y + w3.z * d.z;
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<f32x4 *>(Bf + r * ldb + 4 * q) = v;
+        }
+    }
+    __syncthreads();
+    dense_to_lds<P, true>(Bf, ldb, a.w2, a.b2, a.c1, a.c2, A, lda);
+    __syncthreads();
+    SAArgs l3;  // layer 3 + max reuses the generic epilogue
+    l3.n = a.n, l3.np = a.np, l3.ns = a.ns, l3.cin = 0, l3.c1 = a.c1, l3.c2 = a.c2, l3.c3 = a.c3;
+    l3.xyz = nullptr, l3.feats_in = nullptr, l3.new_xyz = nullptr, l3.idx = nullptr;
+    l3.w1 = l3.b1 = l3.w2 = l3.b2 = nullptr, l3.w3 = a.w3, l3.b3 = a.b3;
+    l3.out = a.out, l3.cout_total = a.cout_total, l3.cout_off = a.cout_off, l3.groupall = 0;
+    const int wn = pick_wn(gp_round16(a.c3) / 16, P, a.ns);
+    if constexpr (P >= 64) {
+        if (wn == 1) return layer3_max<P / 64, 1>(l3, A, lda, c2p, row0, b);
+    }
+    if constexpr (P >= 32) {
+        if (wn == 2) return layer3_max<P / 32, 2>(l3, A, lda, c2p, row0, b);
+    }
+    layer3_max<P / 16, 4>(l3, A, lda, c2p, row0, b);
+}
+
+template <int P>
+int launch_pre(const SAPreArgs &a, int b, hipStream_t st) {
+    const int c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
+    const size_t lds = ((size_t)P * (c2p + c1p + 2 * GP_LD_PAD) + (size_t)P * 4 + P) * sizeof(float);
+    if (lds > 160 * 1024) return GP_EINVAL;
+    auto kern = sa_pre_mlp_kernel<P>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GP_ELAUNCH;
+    }
+    const int nrows = a.np * a.ns;
+    hipLaunchKernelGGL(kern, dim3((nrows + P - 1) / P, b), dim3(256), lds, st, a);
+    return gp_launch_status();
+}
+
 template <int P>
 int launch(const SAArgs &a, int b, hipStream_t st) {
     const int K0p = gp_round16(a.cin + 3), c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
@@ -192,6 +329,38 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
     if (groupall || (ns <= 32 && forced != 64 && !(narrow && forced != 32))) return launch<32>(a, b, st);
     if (lds_bytes(64, a) <= 150 * 1024) return launch<64>(a, b, st);
     return GP_EINVAL;
+}
+
+int gp_point_linear(int rows, int k_in, int n_out, const float *x, const float *wpack, float *z, gp_stream_t s) {
+    if (rows < 0 || k_in <= 0 || (k_in & 3) || n_out <= 0 || (n_out & 3) || !x || !wpack || !z) return GP_EINVAL;
+    if (rows == 0) return GP_OK;
+    const size_t lds = (size_t)64 * (gp_round16(k_in) + GP_LD_PAD) * sizeof(float);
+    if (lds > 160 * 1024) return GP_EINVAL;
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(point_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return GP_ELAUNCH;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(point_linear_kernel, dim3((rows + 63) / 64), dim3(256), lds, (hipStream_t)s, rows, k_in, n_out, x, wpack, z);
+    return gp_launch_status();
+}
+
+int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz, const int32_t *idx,
+                      const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2, const float *bias2,
+                      const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s) {
+    if (b < 0 || n <= 0 || np <= 0 || ns <= 0 || c1 <= 0 || c2 <= 0 || c3 <= 0) return GP_EINVAL;
+    if (!xyz || !new_xyz || !idx || !wxyz || !bias1 || !wpack2 || !bias2 || !wpack3 || !bias3 || !out) return GP_EINVAL;
+    if ((ns % 16) != 0 || ns > 64 || (cout_total & 3) || (cout_off & 3) || (c3 & 3) || cout_off + c3 > cout_total) return GP_EINVAL;
+    if (z && ((zstride & 3) || (zoff & 3) || zoff + c1 > zstride)) return GP_EINVAL;
+    if (b == 0) return GP_OK;
+    SAPreArgs a{n, np, ns, c1, c2, c3, zstride, zoff, xyz, new_xyz, z, idx, wxyz, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off};
+    const bool narrow = c1 <= 64 && c2 <= 64 && c3 <= 64;
+    if (ns <= 32 && !narrow) return launch_pre<32>(a, b, (hipStream_t)s);
+    return launch_pre<64>(a, b, (hipStream_t)s);
 }
 
 int64_t gp_pack_weight_size(int n_out, int k_in) { return (int64_t)(gp_round16(n_out) / 16) * (gp_round16(k_in) / 16) * 256; }

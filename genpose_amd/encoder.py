@@ -31,8 +31,9 @@ class Pointnet2EncoderHIP:
         if ws is not None:
             return ws
         dev = self.device
-        ws = {"fps_idx": [], "new_xyz": [], "bq": [], "feat": []}
+        ws = {"fps_idx": [], "new_xyz": [], "bq": [], "feat": [], "z": []}
         n = N
+        cin = 0
         for k, npnt in enumerate(self.cfg["npoints"]):
             cout = sum(s.couts[-1] for s in self.w.levels[k])
             if npnt is None:
@@ -42,7 +43,9 @@ class Pointnet2EncoderHIP:
             ws["new_xyz"].append(torch.empty(B, npnt, 3, device=dev))
             ws["bq"].append([torch.empty(B, npnt, ns, dtype=torch.int32, device=dev) for ns in self.cfg["nsamples"][k]])
             ws["feat"].append(torch.empty(B, npnt, cout, device=dev))
-            n = npnt
+            zs = sum(s.couts[0] for s in self.w.levels[k])
+            ws["z"].append(torch.empty(B, n, zs, device=dev) if cin > 0 else None)
+            n, cin = npnt, cout
         self._ws[key] = ws
         return ws
 
@@ -95,13 +98,19 @@ class Pointnet2EncoderHIP:
                 for i in range(len(scales)):
                     ws["bq"][k][i].zero_()
                     _lib.call("gp_ball_query", B, n, npnt, float(radii[i]), nss[i], ptr(new_xyz), ptr(xyz), ptr(ws["bq"][k][i]), st)
-            off = 0
+            # first layer hoisted: feature half once per source point, xyz half while gathering (csrc/sa_mlp.hip)
+            z = ws["z"][k]
+            zstride = sum(sc.couts[0] for sc in scales)
+            if z is not None:
+                _lib.call("gp_point_linear", B * n, cin, zstride, ptr(feats), ptr(self.w.z_weights[k]), ptr(z), st)
+            off, zoff = 0, 0
             for i, sc in enumerate(scales):
                 (w1, b1), (w2, b2), (w3, b3) = sc.layers
-                _lib.call("gp_sa_mlp_max", B, n, npnt, nss[i], cin, sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(feats),
-                          ptr(new_xyz), ptr(ws["bq"][k][i]), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out), cout_total,
-                          off, st)
+                _lib.call("gp_sa_pre_mlp_max", B, n, npnt, nss[i], sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(new_xyz),
+                          ptr(ws["bq"][k][i]), ptr(z), zstride, zoff, ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out),
+                          cout_total, off, st)
                 off += sc.couts[2]
+                zoff += sc.couts[0]
             xyz, feats, n, cin = new_xyz, out, npnt, cout_total
         res = feats.reshape(B, -1).clone()
         if return_intermediates:

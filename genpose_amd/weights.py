@@ -70,6 +70,12 @@ class SAScale:
             if l == 0:
                 if Wf.shape[1] != cin_feat + 3:
                     raise ValueError(f"{p}conv.weight has {Wf.shape[1]} input channels, expected {cin_feat + 3}")
+                # hoisted form (csrc/sa_mlp.hip): feature half applied once per source point, xyz half while gathering
+                self.w1_feat = Wf[:, 3:].float().contiguous()  # [c1, cin]
+                c1p = _round16(Wf.shape[0])
+                wxyz = torch.zeros(c1p, 4)
+                wxyz[: Wf.shape[0], :3] = Wf[:, :3].float()
+                self.wxyz = wxyz.to(device)
                 Wf = torch.cat([Wf[:, 3:], Wf[:, :3]], dim=1)  # [dx,dy,dz,feat] -> [feat,dx,dy,dz]
             self.layers.append((pack_weight(Wf.float()).to(device), pad_bias(bf.float()).to(device)))
             self.couts.append(Wf.shape[0])
@@ -84,6 +90,7 @@ class EncoderWeights:
             raise NotImplementedError(params)
         self.cfg = ENCODER_CFGS[params]
         self.levels = []
+        self.z_weights = []
         cin = 0
         for k, level in enumerate(self.cfg["mlps"]):
             scales = [SAScale(sd, f"{prefix}SA_modules.{k}.mlps.{i}.", cin, device) for i in range(len(level))]
@@ -91,6 +98,8 @@ class EncoderWeights:
                 if sc.couts != list(spec):
                     raise ValueError(f"SA level {k}: checkpoint layer widths {sc.couts} != config {spec}")
             self.levels.append(scales)
+            # combined per-point first-layer weights of the level's scales: z = feat . [W1f_0 ; W1f_1]^T
+            self.z_weights.append(pack_weight(torch.cat([sc.w1_feat for sc in scales], dim=0)).to(device) if cin > 0 else None)
             cin = sum(s.couts[-1] for s in scales)
         self.out_dim = cin
 

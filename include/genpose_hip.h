@@ -97,6 +97,17 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
                   const float *bias2, const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off,
                   gp_stream_t s);
 
+/* Hoisted first layer of a grouping level (exact algebra: W1.[feat_j ; xyz_j - c] = W1f.feat_j + W1x.(xyz_j - c)):
+ * gp_point_linear computes z[row, 0:n_out] = x[row, 0:k_in] . W1f^T once per SOURCE point (rows = b*n; wpack from gp_pack_weight);
+ * gp_sa_pre_mlp_max then gathers z rows (channels [zoff, zoff+c1) of a zstride-wide row; z = NULL for a level without input
+ * features), adds wxyz[c][0..2].(xyz_j - centre) + bias1[c], ReLU, and runs layers 2, 3 + max-pool as gp_sa_mlp_max does.
+ * wxyz is [round16(c1)][4] (x, y, z, 0), BN scale folded in.  This is the encoder's production path; gp_sa_mlp_max remains for
+ * the GroupAll level and as the unhoisted form. */
+int gp_point_linear(int rows, int k_in, int n_out, const float *x, const float *wpack, float *z, gp_stream_t s);
+int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz, const int32_t *idx,
+                      const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2, const float *bias2,
+                      const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s);
+
 /* Weight packing for the MFMA layers (host-callable helpers operating on HOST memory):
  * W is [n_out, k_in] row-major (torch Linear / 1x1 conv layout).  Packed size in floats = gp_pack_weight_size(). */
 int64_t gp_pack_weight_size(int n_out, int k_in);
