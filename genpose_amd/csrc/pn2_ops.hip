@@ -69,6 +69,10 @@ struct FpsRank {
         return (uint32_t)(S - 1 - (int)br) * (uint32_t)Q + (uint32_t)(Q - 1 - (k >> logS));
     }
     __device__ __forceinline__ int unrank(uint32_t r) const {
+        if (Q == 1) {  // n <= 1024 and a power of two (every level of the encoder): no division
+            const uint32_t br1 = (uint32_t)(S - 1) - r;
+            return (int)(logS ? (__brev(br1) >> (32 - logS)) : 0u);
+        }
         uint32_t a = r / (uint32_t)Q, bq = r - a * (uint32_t)Q;
         uint32_t br = (uint32_t)(S - 1) - a;
         uint32_t slot = logS ? (__brev(br) >> (32 - logS)) : 0u;
@@ -89,7 +93,7 @@ __device__ __forceinline__ FpsRank make_rank(int n) {
 
 // One FPS pass over the n points held in LDS (sx/sy/sz) selecting m of them.
 // temp_io: optional global running-min buffer (API semantics) - read at start, written back at the end.
-template <int PPT>
+template <int PPT, bool FULL = false>  // FULL: n == PPT * FPS_T exactly (no bounds checks in the hot loop)
 __device__ void fps_pass(int n, int m, const float *sx, const float *sy, const float *sz, float *temp_io,
                          int32_t *idx_out, unsigned long long (*slots)[FPS_T / 64]) {
     const int tid = threadIdx.x;
@@ -114,7 +118,7 @@ __device__ void fps_pass(int n, int m, const float *sx, const float *sy, const f
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             int k = tid + j * FPS_T;
-            if (k < n) {
+            if (FULL || k < n) {
                 float d = sqdist(px[j], py[j], pz[j], x1, y1, z1);
                 float d2 = fminf(d, tmp[j]);
                 tmp[j] = d2;
@@ -230,7 +234,13 @@ __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
     for (int l = 0; l < a.nlevels; ++l) {
         const int m = a.m[l];
         float *sx = cur[buf][0], *sy = cur[buf][1], *sz = cur[buf][2];
-        if (n <= FPS_T)
+        if (n == 4 * FPS_T)
+            fps_pass<4, true>(n, m, sx, sy, sz, nullptr, sel, slots);
+        else if (n == 2 * FPS_T)
+            fps_pass<2, true>(n, m, sx, sy, sz, nullptr, sel, slots);
+        else if (n == FPS_T)
+            fps_pass<1, true>(n, m, sx, sy, sz, nullptr, sel, slots);
+        else if (n <= FPS_T)
             fps_pass<1>(n, m, sx, sy, sz, nullptr, sel, slots);
         else if (n <= 2 * FPS_T)
             fps_pass<2>(n, m, sx, sy, sz, nullptr, sel, slots);

@@ -275,6 +275,132 @@ int launch_pre(const SAPreArgs &a, int b, hipStream_t st) {
     return gp_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Register-resident chain for the narrow first level (no input features; widths <= 64; ~1.6 M rows at B = 64).
+// One WAVE owns one neighbourhood at a time and carries it through all three layers without LDS or barriers:
+//   layer 1 is three FMAs per channel (the hoisted xyz half), computed directly in the MFMA B-operand layout;
+//   the D fragment of v_mfma_f32_16x16x4_f32 (lane = point, 4 consecutive channels of chunk nc) IS the B fragment
+//   the next layer needs for k-group nc, so activations never leave the registers;
+//   all weights of the level (<= 14 KB) are preloaded as A fragments into registers once per wave.
+// The tile-based kernel above spends its time on barriers and dependent global round trips here (measured 111 + 306 us
+// for the two scales at B = 64 against ~10 + 45 us of MFMA work).
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentres_total) {
+    constexpr int PT = NS / 16, Q1 = C1 / 16, Q2 = C2 / 16, Q3 = C3 / 16;
+    const int lane = threadIdx.x & 63, pt = lane & 15, g = lane >> 4;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    // ---- per-lane constants: layer-1 rows for channels 16q + 4g + {0..3}; A fragments of layers 2 and 3; biases
+    f32x4 w1[Q1][4], bb1[Q1];
+#pragma unroll
+    for (int q = 0; q < Q1; ++q) {
+        bb1[q] = *reinterpret_cast<const f32x4 *>(a.b1 + 16 * q + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w1[q][r] = *reinterpret_cast<const f32x4 *>(a.wxyz + (16 * q + 4 * g + r) * 4);
+    }
+    f32x4 w2[Q2][Q1], bb2[Q2], w3[Q3][Q2], bb3[Q3];
+#pragma unroll
+    for (int n = 0; n < Q2; ++n) {
+        bb2[n] = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * n + 4 * g);
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) w2[n][q] = reinterpret_cast<const f32x4 *>(a.w2)[((size_t)q * Q2 + n) * 64 + lane];
+    }
+#pragma unroll
+    for (int n = 0; n < Q3; ++n) {
+        bb3[n] = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * n + 4 * g);
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) w3[n][q] = reinterpret_cast<const f32x4 *>(a.w3)[((size_t)q * Q3 + n) * 64 + lane];
+    }
+    // ---- neighbourhood loop with a two-deep prefetch: idx of centre i+2 and xyz of centre i+1 are in flight while i runs
+    auto centre_ok = [&](int c) { return c < ncentres_total; };
+    auto load_idx = [&](int c, int (&j)[PT]) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) j[p] = centre_ok(c) ? a.idx[(size_t)c * NS + p * 16 + pt] : 0;
+    };
+    auto load_d = [&](int c, const int (&j)[PT], float (&d)[PT][3]) {
+        const int cc = centre_ok(c) ? c : 0;
+        const int bcl = cc / a.np;
+        const float *xyz = a.xyz + (size_t)bcl * a.n * 3;
+        const float *cp = a.new_xyz + (size_t)cc * 3;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            d[p][0] = xyz[j[p] * 3 + 0] - cx;  // grouped_xyz -= new_xyz (pointnet2_utils.py:253)
+            d[p][1] = xyz[j[p] * 3 + 1] - cy;
+            d[p][2] = xyz[j[p] * 3 + 2] - cz;
+        }
+    };
+    int c = wave_global;
+    int jn[PT], jnn[PT];
+    float dcur[PT][3], dn[PT][3];
+    load_idx(c, jn);
+    load_d(c, jn, dcur);
+    load_idx(c + nwaves, jn);
+    for (; c < ncentres_total; c += nwaves) {
+        load_d(c + nwaves, jn, dn);
+        load_idx(c + 2 * nwaves, jnn);
+        f32x4 res[Q3];
+#pragma unroll
+        for (int n = 0; n < Q3; ++n) res[n] = f32x4{0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const float dx = dcur[p][0], dy = dcur[p][1], dz = dcur[p][2];
+            f32x4 h1[Q1], h2[Q2];
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) {
+                f32x4 v = bb1[q];
+                v.x += w1[q][0].x * dx + w1[q][0].y * dy + w1[q][0].z * dz;
+                v.y += w1[q][1].x * dx + w1[q][1].y * dy + w1[q][1].z * dz;
+                v.z += w1[q][2].x * dx + w1[q][2].y * dy + w1[q][2].z * dz;
+                v.w += w1[q][3].x * dx + w1[q][3].y * dy + w1[q][3].z * dz;
+                h1[q] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+            }
+#pragma unroll
+            for (int n = 0; n < Q2; ++n) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < Q1; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[n][q][jj], h1[q][jj], acc, 0, 0, 0);
+                acc += bb2[n];
+                h2[n] = f32x4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+            }
+#pragma unroll
+            for (int n = 0; n < Q3; ++n) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < Q2; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[n][q][jj], h2[q][jj], acc, 0, 0, 0);
+                acc += bb3[n];
+                res[n].x = fmaxf(res[n].x, acc.x);
+                res[n].y = fmaxf(res[n].y, acc.y);
+                res[n].z = fmaxf(res[n].z, acc.z);
+                res[n].w = fmaxf(res[n].w, acc.w);
+            }
+        }
+        float *o = a.out + (size_t)c * a.cout_total + a.cout_off;
+#pragma unroll
+        for (int n = 0; n < Q3; ++n) {
+            f32x4 m = {row16_max(res[n].x), row16_max(res[n].y), row16_max(res[n].z), row16_max(res[n].w)};
+            if (pt == 0) *reinterpret_cast<f32x4 *>(o + 16 * n + 4 * g) = m;
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            dcur[p][0] = dn[p][0], dcur[p][1] = dn[p][1], dcur[p][2] = dn[p][2];
+            jn[p] = jnn[p];
+        }
+    }
+}
+
+template <int C1, int C2, int C3, int NS>
+int launch_chain(const SAPreArgs &a, int b, hipStream_t st) {
+    const int ncentres = b * a.np;
+    int blocks = (ncentres + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: <= 8 workgroups per CU resident, weights loaded once per wave
+    hipLaunchKernelGGL((sa0_chain_kernel<C1, C2, C3, NS>), dim3(blocks), dim3(256), 0, st, a, ncentres);
+    return gp_launch_status();
+}
+
 template <int P>
 int launch(const SAArgs &a, int b, hipStream_t st) {
     const int K0p = gp_round16(a.cin + 3), c1p = gp_round16(a.c1), c2p = gp_round16(a.c2);
@@ -358,6 +484,12 @@ int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, cons
     if (z && ((zstride & 3) || (zoff & 3) || zoff + c1 > zstride)) return GP_EINVAL;
     if (b == 0) return GP_OK;
     SAPreArgs a{n, np, ns, c1, c2, c3, zstride, zoff, xyz, new_xyz, z, idx, wxyz, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off};
+    static int nochain = -1;  // GP_SA_NOCHAIN=1 forces the tile kernel (tuning / A-B tests)
+    if (nochain < 0) nochain = getenv("GP_SA_NOCHAIN") ? 1 : 0;
+    if (!z && !nochain) {
+        if (c1 == 16 && c2 == 16 && c3 == 32 && ns == 16) return launch_chain<16, 16, 32, 16>(a, b, (hipStream_t)s);
+        if (c1 == 32 && c2 == 32 && c3 == 64 && ns == 32) return launch_chain<32, 32, 64, 32>(a, b, (hipStream_t)s);
+    }
     const bool narrow = c1 <= 64 && c2 <= 64 && c3 <= 64;
     if (ns <= 32 && !narrow) return launch_pre<32>(a, b, (hipStream_t)s);
     return launch_pre<64>(a, b, (hipStream_t)s);
