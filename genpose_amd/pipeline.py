@@ -23,10 +23,12 @@ class PipelinedPCPredictor:
         self.net._need_weights()
         self.B, self.K, self.n, self.depth = B, K, num_steps, depth
         self.dev = self.net.device
-        self.s_enc = torch.cuda.Stream(self.dev)
+        # the sampler is a latency-critical serial chain of short launches: its stream gets the HIGH hardware queue
+        # priority so its workgroups are dispatched ahead of the encoder's thousands of queued workgroups
+        self.s_enc = torch.cuda.Stream(self.dev, priority=0)
         # (sampler_streams > 1 puts several sampler chains in flight; measured SLOWER at the bench configuration:
         #  13.1 k vs 14.2 k poses/s - the chains contend for the same MFMA pipes and each step boundary gets longer)
-        self.s_smp = [torch.cuda.Stream(self.dev) for _ in range(sampler_streams)]
+        self.s_smp = [torch.cuda.Stream(self.dev, priority=-1) for _ in range(sampler_streams)]
         self.smp = [PCSampler(self.net.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False)
                     for _ in range(sampler_streams)]
         self.timing = False
@@ -38,6 +40,7 @@ class PipelinedPCPredictor:
         self.ev_enc = [torch.cuda.Event() for _ in range(depth)]
         self.ev_free = [torch.cuda.Event() for _ in range(depth)]
         self.prior_host = [torch.empty(R, 9).pin_memory() for _ in range(depth)]
+        self.ev_h2d = [torch.cuda.Event() for _ in range(depth)]  # the async H2D copy out of prior_host[slot] has completed
         for e in self.ev_free:
             e.record(self.s_smp[0])
 
@@ -59,8 +62,10 @@ class PipelinedPCPredictor:
                 self.cvec[slot].copy_(cv)
                 self.centre[slot].copy_(pts.mean(dim=1))
                 if prior_noise is None:
+                    self.ev_h2d[slot].synchronize()  # host may run `depth` batches ahead, not further (pinned buffer reuse)
                     torch.randn(self.prior_host[slot].shape, out=self.prior_host[slot])  # CPU generator, as sde.py:28
                     self.x0[slot].copy_(self.prior_host[slot], non_blocking=True)
+                    self.ev_h2d[slot].record(self.s_enc)
                 else:
                     self.x0[slot].copy_(prior_noise[i])
                 self.x0[slot].mul_(SIGMA_MAX)  # prior std at T = 1 (cond_pc_sampler always starts from T = 1)
