@@ -48,6 +48,7 @@ SIGNATURES = {
     "gp_pc_step": [c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
     "gp_rk45_state_bytes": [],
     "gp_rk45_state_layout": [ctypes.POINTER(c_int64), c_int],
+    "gp_rk45_set_dense": [P, P, c_int, P, P],
     "gp_rk45_phase": [c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
     "gp_rank_aggregate": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
 }

@@ -42,6 +42,11 @@ struct Rk45State {
     int step_rejected;     // a rejection happened since the last accepted step
     int n_attempts, n_accepted, nfev;
     int traj_cap;
+    // dense output (solve_ivp with t_eval): emit the t_eval points passed by the accepted step [emit_begin, emit_end)
+    int n_eval, next_eval, emit_begin, emit_end;
+    double t_old, h_acc;    // start and signed size of the last accepted step (st->h is already the NEXT attempt's)
+    const double *t_eval;   // device array [n_eval]
+    double Pm[7][4];        // RK45 dense-output matrix P (passed from the host, scipy's published constants)
     float stage_t[8];      // f32 times fed to the network (stages 1..6 at [1..6]; [0] = misc evaluations)
     float stage_sigma[8];  // f32 sigma(t) the network divides by (scorenet.py:205,217)
     double stage_g2[8];    // f64 g(t)^2 of the PF-ODE right-hand side (sde.py:20-24 on a 0-dim f64 tensor)
@@ -260,7 +265,16 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
                 double factor = (err == 0.0) ? MAX_FACTOR : fmin(MAX_FACTOR, SAFETY * pow(err, -0.2));
                 if (st->step_rejected) factor = fmin(1.0, factor);
                 h_abs *= factor;
+                st->t_old = st->t;
+                st->h_acc = st->h;
                 st->t = st->t + st->h;  // t_new (already clamped to t_bound in begin_attempt)
+                if (st->n_eval > 0) {   // ivp.py: every not-yet-emitted t_eval point the step has passed (inclusive of t_new)
+                    int m = st->next_eval;
+                    st->emit_begin = m;
+                    while (m < st->n_eval && st->direction * (st->t_eval[m] - st->t) <= 0) ++m;
+                    st->emit_end = m;
+                    st->next_eval = m;
+                }
                 st->last_accepted = 1;
                 st->step_rejected = 0;
                 st->n_accepted += 1;
@@ -280,9 +294,32 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
 __global__ void rk45_record_kernel(OdeArgs a) {
     const Rk45State *st = a.st;
     if (!a.traj || !st->last_accepted) return;
+    const size_t n = (size_t)a.nrows * 9;
+    if (st->n_eval > 0) {
+        // 4th-order dense output of the step just accepted (rk.py RkDenseOutput): y(t) = y_old + h * Q . [x, x^2, x^3, x^4],
+        // Q = K^T P, x = (t - t_old) / h.  y is still y_old here (the commit happens in the next attempt's first stage).
+        const int mb = st->emit_begin, me = st->emit_end;
+        if (mb >= me) return;
+        const double h = st->h_acc, t_old = st->t_old;
+        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+            double Q[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int sgi = 0; sgi < 7; ++sgi) {
+                const double kv = a.K[(size_t)sgi * n + e];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Q[c] += kv * st->Pm[sgi][c];
+            }
+            const double y0 = a.y[e];
+            for (int m = mb; m < me; ++m) {
+                const double x = (st->t_eval[m] - t_old) / h;
+                const double x2 = x * x;
+                a.traj[(size_t)m * n + e] = y0 + h * (Q[0] * x + Q[1] * x2 + Q[2] * (x2 * x) + Q[3] * (x2 * x2));
+            }
+        }
+        return;
+    }
     const int slot = st->n_accepted;  // slot 0 holds y0
     if (slot >= st->traj_cap) return;
-    const size_t n = (size_t)a.nrows * 9;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
         a.traj[(size_t)slot * n + e] = a.ynew[e];
 }
@@ -355,11 +392,22 @@ __global__ void rk45_reset_kernel(Rk45State *st, double t0, double t_bound, doub
     st->h = 0, st->h_abs = 0, st->d0 = st->d1 = st->h0 = 0, st->err_norm = 0;
     st->status = 0, st->last_accepted = 0, st->step_rejected = 0;
     st->n_attempts = 0, st->n_accepted = 0, st->nfev = 0, st->traj_cap = traj_cap;
+    st->n_eval = 0, st->next_eval = 0, st->emit_begin = 0, st->emit_end = 0, st->t_old = t0, st->t_eval = nullptr;
     // the very first evaluation gets a python-float t: sde_coeff(torch.tensor(t)) is f32 there;
     // the f64 formula differs by <= 1e-7 relative - documented deviation.
     for (int i = 0; i < 8; ++i) st->stage_t[i] = 0.f, st->stage_sigma[i] = 1.f, st->stage_g2[i] = 0.0;
     set_stage(st, 0, t0);
     (void)eps_time;
+}
+
+struct DenseP {
+    double p[7][4];
+};
+__global__ void rk45_set_dense_kernel(Rk45State *st, const double *t_eval, int n_eval, DenseP P) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->t_eval = t_eval, st->n_eval = n_eval, st->next_eval = 0, st->emit_begin = st->emit_end = 0;
+    for (int i = 0; i < 7; ++i)
+        for (int c = 0; c < 4; ++c) st->Pm[i][c] = P.p[i][c];
 }
 
 __global__ void rk45_set_slot0_kernel(Rk45State *st, double t) {
@@ -432,6 +480,18 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
 extern "C" {
 
 int64_t gp_rk45_state_bytes(void) { return (int64_t)sizeof(Rk45State); }
+
+/* Dense-output mode (solve_ivp(..., t_eval=...)): call after phase 0.  t_eval: device array [n_eval] f64 (monotone in the
+ * integration direction, as np.linspace(T0, eps, n)); P: the 7x4 dense-output matrix of RK45 in HOST memory (row-major;
+ * scipy.integrate RK45.P).  traj must then hold [n_eval][R*9]: slot m receives the interpolated state at t_eval[m]. */
+int gp_rk45_set_dense(void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s) {
+    if (!state || !t_eval_dev || n_eval <= 0 || !P_host) return GP_EINVAL;
+    DenseP P;
+    for (int i = 0; i < 7; ++i)
+        for (int c = 0; c < 4; ++c) P.p[i][c] = P_host[i * 4 + c];
+    hipLaunchKernelGGL(rk45_set_dense_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (Rk45State *)state, t_eval_dev, n_eval, P);
+    return gp_launch_status();
+}
 
 /* Field offsets for host-side inspection: fills out[0..15] with byte offsets of
  * t, h_abs, status, n_attempts, n_accepted, nfev, err_norm, log_t, log_h, log_err, log_acc, stage_t, last_accepted */

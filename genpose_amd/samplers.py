@@ -128,6 +128,7 @@ class ODESampler:
         self.use_graph, self.poll = use_graph, poll
         self.graph = None
         self.graph_traj = None
+        self.graph_dense = None
         self.last_stats = {}
 
     def _phase(self, phase, traj=None, t0=0.0, t_bound=0.0, rtol=1e-5, atol=1e-5, dscale=0.0, do_denoise=1, nstates=0):
@@ -162,18 +163,31 @@ class ODESampler:
             max_attempts=4096):
         """Returns (xs [R,S,9] f64 or None, x [R,9] f64).  With num_steps=None the in-process samples are the accepted
         states (like solve_ivp without t_eval)."""
-        if return_process and num_steps is not None:
-            raise NotImplementedError("in-process samples at t_eval points need RK45 dense output (not on the hot path yet); "
-                                      "use sampling_steps=None or return_process=False")
+        dense = return_process and num_steps is not None
         self.cvec.copy_(cvec)
         self.centre.copy_(centre)
         self.y.copy_(init_x.reshape(-1).double())  # init_x f32 -> f64 state (solve_ivp casts y0 to float64)
         traj = None
-        if return_process:
-            if self.traj is None:
-                self.traj = torch.zeros(self.TRAJ_CAP, self.R * 9, dtype=torch.float64, device=self.dev)
-            traj = self.traj
-        self._phase(0, traj, t0=T0, t_bound=eps, rtol=rtol, atol=atol)
+        if dense:
+            # solve_ivp(t_eval=np.linspace(T0, eps, num_steps)): 4th-order dense output at every t_eval point
+            import ctypes
+            from scipy.integrate._ivp.rk import RK45  # published dense-output constants (7x4 matrix P)
+            key = ("dense", num_steps)
+            if getattr(self, "_dense_key", None) != key:
+                self._dense_traj = torch.zeros(num_steps, self.R * 9, dtype=torch.float64, device=self.dev)
+                self._dense_key = key
+                self.graph_dense = None  # the captured attempt holds the trajectory pointer
+            self._t_eval = torch.from_numpy(np.linspace(T0, eps, num_steps)).to(self.dev)
+            traj = self._dense_traj
+            self._phase(0, None, t0=T0, t_bound=eps, rtol=rtol, atol=atol)
+            Pm = np.ascontiguousarray(RK45.P, dtype=np.float64)
+            _lib.call("gp_rk45_set_dense", ptr(self.state), ptr(self._t_eval), num_steps, Pm.ctypes.data_as(ctypes.c_void_p), stream_ptr())
+        else:
+            if return_process:
+                if self.traj is None:
+                    self.traj = torch.zeros(self.TRAJ_CAP, self.R * 9, dtype=torch.float64, device=self.dev)
+                traj = self.traj
+            self._phase(0, traj, t0=T0, t_bound=eps, rtol=rtol, atol=atol)
         self._embed()
         self._phase(1, traj)
         self._embed()
@@ -181,7 +195,7 @@ class ODESampler:
         n_done = 0
         while True:
             if self.use_graph:
-                gname = "graph_traj" if traj is not None else "graph"
+                gname = "graph_dense" if dense else ("graph_traj" if traj is not None else "graph")
                 if getattr(self, gname) is None:
                     self._attempt(traj)  # warm-up outside capture
                     n_done += 1
@@ -204,8 +218,8 @@ class ODESampler:
             raise RuntimeError("ODE sampler: required step size is less than spacing between numbers (scipy TOO_SMALL_STEP)")
         self._phase(4, traj, t0=eps)
         self._embed()
-        nstates = int(st["n_accepted"]) + 1 if traj is not None else 0
-        if traj is not None and nstates > self.TRAJ_CAP:
+        nstates = (num_steps if dense else int(st["n_accepted"]) + 1) if traj is not None else 0
+        if traj is not None and not dense and nstates > self.TRAJ_CAP:
             raise RuntimeError(f"ODE sampler: {nstates} accepted states exceed the trajectory capacity {self.TRAJ_CAP}")
         dscale = (1 - eps) / (1000 if num_steps is None else num_steps)
         self._phase(5, traj, dscale=dscale, do_denoise=1 if denoise else 0, nstates=nstates)

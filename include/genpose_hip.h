@@ -177,6 +177,10 @@ int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net,
  *     and the same post-processing of the first `nstates` trajectory states.
  * Before phases 1, 2, every 3 and 5 the caller refreshes tvec = gp_time_embed(8, net, state + offset(stage_t), tvec). */
 int64_t gp_rk45_state_bytes(void);
+/* Dense-output mode = solve_ivp(..., t_eval=np.linspace(T0, eps, n)) (samplers.py:201-205): call after phase 0 with traj = NULL
+ * there; t_eval_dev [n_eval] f64 on the device, P_host = RK45's 7x4 dense-output matrix (row-major, HOST memory).  traj
+ * [n_eval][R*9] then receives the 4th-order interpolant at every t_eval point (scipy RkDenseOutput). */
+int gp_rk45_set_dense(void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s);
 int gp_rk45_state_layout(int64_t *offsets, int n); /* n >= 13: t,h_abs,status,n_attempts,n_accepted,nfev,err_norm,log_t,log_h,log_err,log_acc,stage_t,last_accepted */
 int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre,
                   void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap, double t0,

@@ -51,9 +51,9 @@ def test_ode_golden(golden, case):
     init_x = torch.from_numpy(g[f"{case}_init_x"]).cuda() if f"{case}_init_x" in g else None
     data = {"pts": pts, "pts_center": pts.mean(dim=1)}
     with FixedPrior(agent, g[f"{case}_prior_noise"]):
-        want_proc = steps < 0
+        want_proc = True  # steps < 0: accepted states; steps given: RK45 dense output at the t_eval points
         out = agent.pred_func(data, repeat_num=10, save_path=None, T0=float(g[f"{case}_T0"]), init_x=init_x, return_process=want_proc)
-    pred, proc = (out if want_proc else (out, None))
+    pred, proc = out
     assert pred.dtype == torch.float64 and "pts_feat" in data
     ode_close(pred.cpu().numpy(), g[f"{case}_pred"])
     stats = agent.net._samplers[("ode", 2, 10)].last_stats
@@ -63,8 +63,11 @@ def test_ode_golden(golden, case):
     assert abs(int(stats["nfev"]) - ref_nfev) <= 12, (stats["nfev"], ref_nfev)
     if int(stats["nfev"]) == ref_nfev:
         ref_t = g[f"{case}_eval_t"]
-        # first stage evaluation of every attempt sits at t + h/5 (Dormand-Prince c_2); the reference logged f32 times
-        np.testing.assert_allclose(stats["log_t"] + 0.2 * stats["log_h"], ref_t[2:-1:6][: len(stats["log_t"])], rtol=1e-4, atol=5e-6)
+        # same accept/reject sequence, and every attempt starts where the reference's did: first stage evaluation of an
+        # attempt sits at t + h/5 (Dormand-Prince c_2).  Step sizes follow err^(-1/5), so fp32-level differences in the
+        # score move them by ~1e-3 relative late in the integration; the reference logged f32 times.
+        assert [bool(a) for a in stats["log_acc"]] == _ref_accepts(ref_t)
+        np.testing.assert_allclose(stats["log_t"] + 0.2 * stats["log_h"], ref_t[2:-1:6][: len(stats["log_t"])], rtol=2e-3, atol=2e-5)
     if proc is not None and int(stats["nfev"]) == ref_nfev:
         assert list(proc.shape) == list(g[f"{case}_proc_shape"])
         ode_close(proc[:, :, -3:].cpu().numpy(), g[f"{case}_proc_last3"])
@@ -121,6 +124,21 @@ def test_rank_ties_and_sizes():
         np.testing.assert_allclose(r["avg_pose"].cpu().numpy()[:, 4:], qt.numpy()[:, 4:], atol=1e-5)
         dot = np.abs(np.sum(r["avg_pose"].cpu().numpy()[:, :4] * qt.numpy()[:, :4], axis=1))
         assert np.all(dot > 1 - 1e-4)
+
+
+def _ref_accepts(ref_t):
+    """Accept/reject sequence of the reference run, recovered from its logged evaluation times: after a REJECTED attempt
+    the next attempt restarts from the same t (its first stage time t + h'/5 lies before the rejected attempt's last
+    stage time t + h), after an accepted one it starts from t + h."""
+    first = ref_t[2:-1:6]   # t + h/5 of every attempt
+    last = ref_t[7::6]      # t + h   of every attempt (6th evaluation)
+    acc = []
+    for i in range(len(first)):
+        if i + 1 < len(first):
+            acc.append(bool(first[i + 1] < last[i]))  # integrating DOWN in t: next attempt begins beyond t + h  <=> accepted
+        else:
+            acc.append(True)
+    return acc
 
 
 def _ref_sorted(poses, order):
