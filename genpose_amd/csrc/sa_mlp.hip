@@ -392,6 +392,177 @@ __global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentre
     }
 }
 
+// Same register-resident chain for a level WITH input features (hoisted first layer: h1 = relu(Z[j] + W1x.dxyz + b1)).
+// The layer-2/3 weights (48-72 KB for the light config's second level) no longer fit the register file, so they are
+// copied ONCE per workgroup into LDS in A-fragment order and every wave streams its fragments from there
+// (ds_read_b128, 1 KB per wave-instruction, lane-linear = conflict free) while it walks its own neighbourhoods:
+// no L2 weight traffic after the prologue, no LDS activation traffic, no barriers in the loop.
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncentres_total) {
+    constexpr int PT = NS / 16, Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4 *w2l = reinterpret_cast<f32x4 *>(lds);           // [Q1][Q2][64]
+    f32x4 *w3l = w2l + Q1 * Q2 * 64;                        // [Q2][Q3][64]
+    f32x4 *w1l = w3l + Q2 * Q3 * 64;                        // [C1] rows (wx, wy, wz, b1)
+    const int tid = threadIdx.x, lane = tid & 63, pt = lane & 15, g = lane >> 4;
+    for (int e = tid; e < Q1 * Q2 * 64; e += 256) w2l[e] = reinterpret_cast<const f32x4 *>(a.w2)[e];
+    for (int e = tid; e < Q2 * Q3 * 64; e += 256) w3l[e] = reinterpret_cast<const f32x4 *>(a.w3)[e];
+    for (int e = tid; e < C1; e += 256) {
+        f32x4 w = *reinterpret_cast<const f32x4 *>(a.wxyz + e * 4);
+        w.w = a.b1[e];
+        w1l[e] = w;
+    }
+    f32x4 bb2[Q2], bb3[Q3];
+#pragma unroll
+    for (int n = 0; n < Q2; ++n) bb2[n] = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * n + 4 * g);
+#pragma unroll
+    for (int n = 0; n < Q3; ++n) bb3[n] = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * n + 4 * g);
+    __syncthreads();
+    const int wave_global = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
+    // The wave walks 16-row chunks: iteration `it` is chunk p = it % PT of the wave's (it / PT)-th neighbourhood, so the
+    // per-iteration register footprint is one chunk whatever the neighbourhood size (the running max lives in `res`).
+    const int my_centres = wave_global < ncentres_total ? (ncentres_total - wave_global + nwaves - 1) / nwaves : 0;
+    const int nits = my_centres * PT;
+    auto chunk_row0 = [&](int it, int &c) {
+        c = wave_global + (it / PT) * nwaves;
+        return (size_t)c * NS + (size_t)(it % PT) * 16;
+    };
+    auto load_idx = [&](int it) {
+        int c;
+        const size_t r0 = chunk_row0(it, c);
+        return it < nits ? a.idx[r0 + pt] : 0;
+    };
+    // operands of one chunk: xyz deltas and the gathered rows of Z (this lane's channels 16q + 4g + 0..3)
+    auto load_ops = [&](int it, int j, float (&d)[3], f32x4 (&zz)[Q1]) {
+        int c;
+        chunk_row0(it, c);
+        const int cc = it < nits ? c : 0;
+        const int bcl = cc / a.np;
+        const float *xyz = a.xyz + (size_t)bcl * a.n * 3;
+        const float *zb = a.z + (size_t)bcl * a.n * a.zstride + a.zoff;
+        const float *cp = a.new_xyz + (size_t)cc * 3;
+        d[0] = xyz[j * 3 + 0] - cp[0];  // grouped_xyz -= new_xyz (pointnet2_utils.py:253)
+        d[1] = xyz[j * 3 + 1] - cp[1];
+        d[2] = xyz[j * 3 + 2] - cp[2];
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) zz[q] = *reinterpret_cast<const f32x4 *>(zb + (size_t)j * a.zstride + 16 * q + 4 * g);
+    };
+    int jn, jnn;
+    float dcur[3], dn[3];
+    f32x4 zcur[Q1], zn[Q1];
+    jn = load_idx(0);
+    load_ops(0, jn, dcur, zcur);
+    jn = load_idx(1);
+    f32x4 res[Q3];
+#pragma unroll 1
+    for (int it = 0; it < nits; ++it) {
+        load_ops(it + 1, jn, dn, zn);
+        jnn = load_idx(it + 2);
+        // the weight fragments are loop-invariant LDS reads: launder the lane offset so hipcc keeps them as streamed
+        // ds_read_b128 inside the loop instead of hoisting all (Q1*Q2 + Q2*Q3) fragments into registers (spills)
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int p = it % PT;
+        if (p == 0) {
+#pragma unroll
+            for (int n = 0; n < Q3; ++n) res[n] = f32x4{0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0
+        }
+        {
+            const float dx = dcur[0], dy = dcur[1], dz = dcur[2];
+            f32x4 h1[Q1], h2[Q2];
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) {
+                const int g4 = (lo >> 4) * 4;
+                const f32x4 r0 = w1l[16 * q + g4 + 0], r1 = w1l[16 * q + g4 + 1], r2 = w1l[16 * q + g4 + 2], r3 = w1l[16 * q + g4 + 3];
+                f32x4 v = zcur[q];
+                v.x += (r0.x * dx + r0.y * dy + r0.z * dz) + r0.w;
+                v.y += (r1.x * dx + r1.y * dy + r1.z * dz) + r1.w;
+                v.z += (r2.x * dx + r2.y * dy + r2.z * dz) + r2.w;
+                v.w += (r3.x * dx + r3.y * dy + r3.z * dz) + r3.w;
+                h1[q] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+            }
+            // layer 2: two output chunks in flight (independent accumulators hide the 40-cycle dependent MFMA latency)
+#pragma unroll
+            for (int n0 = 0; n0 < Q2; n0 += 2) {
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int q = 0; q < Q1; ++q) {
+                    f32x4 wf[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) wf[u] = (n0 + u < Q2) ? w2l[(q * Q2 + n0 + u) * 64 + lo] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (n0 + u < Q2) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h1[q][jj], acc[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (n0 + u < Q2) {
+                        f32x4 v = acc[u] + bb2[n0 + u];
+                        h2[n0 + u] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                    }
+            }
+            // layer 3 + running max over the neighbourhood's chunks: four output chunks in flight
+#pragma unroll
+            for (int n0 = 0; n0 < Q3; n0 += 4) {
+                f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int q = 0; q < Q2; ++q) {
+                    f32x4 wf[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wf[u] = w3l[(q * Q3 + n0 + u) * 64 + lo];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h2[q][jj], acc[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 v = acc[u] + bb3[n0 + u];
+                    res[n0 + u].x = fmaxf(res[n0 + u].x, v.x);
+                    res[n0 + u].y = fmaxf(res[n0 + u].y, v.y);
+                    res[n0 + u].z = fmaxf(res[n0 + u].z, v.z);
+                    res[n0 + u].w = fmaxf(res[n0 + u].w, v.w);
+                }
+            }
+        }
+        if (p == PT - 1) {
+            const int c = wave_global + (it / PT) * nwaves;
+            float *o = a.out + (size_t)c * a.cout_total + a.cout_off;
+#pragma unroll
+            for (int n = 0; n < Q3; ++n) {
+                f32x4 m = {row16_max(res[n].x), row16_max(res[n].y), row16_max(res[n].z), row16_max(res[n].w)};
+                if (pt == 0) *reinterpret_cast<f32x4 *>(o + 16 * n + 4 * g) = m;
+            }
+        }
+        dcur[0] = dn[0], dcur[1] = dn[1], dcur[2] = dn[2];
+        jn = jnn;
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) zcur[q] = zn[q];
+    }
+}
+
+template <int C1, int C2, int C3, int NS>
+int launch_chain_lds(const SAPreArgs &a, int b, hipStream_t st) {
+    constexpr int Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16;
+    static_assert(Q3 % 4 == 0, "layer-3 width must be a multiple of 64");
+    const size_t lds = ((size_t)(Q1 * Q2 + Q2 * Q3) * 64 + C1) * sizeof(f32x4);
+    auto kern = sa_chain_lds_kernel<C1, C2, C3, NS>;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GP_ELAUNCH;
+        done = true;
+    }
+    const int ncentres = b * a.np;
+    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;
+    int blocks = (ncentres + 3) / 4;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // persistent: weights are staged once per workgroup
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a, ncentres);
+    return gp_launch_status();
+}
+
 template <int C1, int C2, int C3, int NS>
 int launch_chain(const SAPreArgs &a, int b, hipStream_t st) {
     const int ncentres = b * a.np;
@@ -489,6 +660,10 @@ int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, cons
     if (!z && !nochain) {
         if (c1 == 16 && c2 == 16 && c3 == 32 && ns == 16) return launch_chain<16, 16, 32, 16>(a, b, (hipStream_t)s);
         if (c1 == 32 && c2 == 32 && c3 == 64 && ns == 32) return launch_chain<32, 32, 64, 32>(a, b, (hipStream_t)s);
+    }
+    if (z && !nochain && (zoff % 4) == 0 && (zstride % 4) == 0) {
+        if (c1 == 64 && c2 == 64 && c3 == 128 && ns == 16) return launch_chain_lds<64, 64, 128, 16>(a, b, (hipStream_t)s);
+        if (c1 == 64 && c2 == 96 && c3 == 128 && ns == 32) return launch_chain_lds<64, 96, 128, 32>(a, b, (hipStream_t)s);
     }
     const bool narrow = c1 <= 64 && c2 <= 64 && c3 <= 64;
     if (ns <= 32 && !narrow) return launch_pre<32>(a, b, (hipStream_t)s);
