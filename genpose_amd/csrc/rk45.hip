@@ -80,7 +80,9 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     if ((tid & 63) == 0) sh[tid >> 6] = v;
     __syncthreads();
-    double s = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    const int nw = blockDim.x >> 6;  // 4 or 8 waves; fixed summation order
+    double s = sh[0];
+    for (int w = 1; w < nw; ++w) s += sh[w];
     __syncthreads();
     return s;
 }
@@ -88,16 +90,16 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 // Fused stage kernel.  STAGE 1..6: Runge-Kutta stage;  STAGE 0: f0 = fun(t0, y0) (+ d0,d1 partials);
 // STAGE 7: f1 = fun(t0 + h0*dir, y0 + h0*dir*f0) (+ d2 partial).
 template <int P, int STAGE>
-__global__ __launch_bounds__(256, 2) void rk45_stage_kernel(OdeArgs a, gp_scorenet net) {
+__global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, gp_scorenet net) {
     using L = TrunkLds<P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ double sh[4];
+    __shared__ double sh[8];
     const int row0 = blockIdx.x * P, tid = threadIdx.x;
     Rk45State *st = a.st;
     if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
     const size_t n = (size_t)a.nrows * 9;
     const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
-    TrunkPre pre;
+    TrunkPre<P> pre;
     trunk_begin<P>(net, pre);
     const double h = st->h;
     if (tid < P) {
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void rk45_stage_kernel(OdeArgs a, gp_scoren
     const float *F = lds + L::OFF_H1;
     double *Kout = a.K + (size_t)(STAGE == 7 ? 1 : (STAGE == 0 ? 0 : (STAGE == 6 ? 6 : STAGE))) * n;
     double acc0 = 0.0, acc1 = 0.0;
-    for (int e = tid; e < P * POSE; e += 256) {
+    for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
         const int r = e / POSE, j = e - r * POSE;
         if (row0 + r >= a.nrows) continue;
         const size_t ge = (size_t)(row0 + r) * 9 + j;
@@ -213,7 +215,7 @@ __device__ void begin_attempt(Rk45State *st) {
 // mode 0: after f0 (d0, d1 -> h0, stage slot 0 = t0 + h0*dir);  mode 1: after f1 (d2 -> h_abs, first attempt);
 // mode 2: after an attempt (error norm -> accept / reject -> next attempt)
 __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
-    __shared__ double sh[4];
+    __shared__ double sh[8];
     Rk45State *st = a.st;
     const double nn = (double)a.nrows * 9.0;
     if (mode == 0) {
@@ -326,13 +328,13 @@ __global__ void rk45_record_kernel(OdeArgs a) {
 
 // Denoise (samplers.py:209-218) + normalize_rotation + centre (:224-226); also post-processes the trajectory.
 template <int P>
-__global__ __launch_bounds__(256, 2) void rk45_finish_kernel(OdeArgs a, gp_scorenet net, double denoise_scale, int do_denoise, double *x_out) {
+__global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a, gp_scorenet net, double denoise_scale, int do_denoise, double *x_out) {
     using L = TrunkLds<P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int row0 = blockIdx.x * P, tid = threadIdx.x;
     const Rk45State *st = a.st;
     const double *yfin = st->last_accepted ? a.ynew : a.y;
-    TrunkPre pre;
+    TrunkPre<P> pre;
     trunk_begin<P>(net, pre);
     if (tid < P) {
         const int r = row0 + tid < a.nrows ? row0 + tid : a.nrows - 1;
@@ -437,7 +439,7 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             return GP_ELAUNCH;
         attr_done = true;
     }
-    const dim3 grid(a.nblocks), blk(256);
+    const dim3 grid(a.nblocks), blk(TrunkCfg<P>::NT), blk1(256);
     const size_t n = (size_t)a.nrows * 9;
     switch (phase) {
         case 0:
@@ -446,11 +448,11 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             break;
         case 1:
             hipLaunchKernelGGL((rk45_stage_kernel<P, 0>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 0);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk1, 0, st, a, 0);
             break;
         case 2:
             hipLaunchKernelGGL((rk45_stage_kernel<P, 7>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 1);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk1, 0, st, a, 1);
             break;
         case 3:
             hipLaunchKernelGGL((rk45_stage_kernel<P, 1>), grid, blk, lds, st, a, *net);
@@ -459,8 +461,8 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             hipLaunchKernelGGL((rk45_stage_kernel<P, 4>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL((rk45_stage_kernel<P, 5>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL((rk45_stage_kernel<P, 6>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk, 0, st, a, 2);
-            if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64), blk, 0, st, a);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk1, 0, st, a, 2);
+            if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64), blk1, 0, st, a);
             break;
         case 4:
             hipLaunchKernelGGL(rk45_set_slot0_kernel, dim3(1), dim3(64), 0, st, a.st, t0);
@@ -469,7 +471,7 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             if (!x_out) return GP_EINVAL;
             hipLaunchKernelGGL((rk45_finish_kernel<P>), grid, blk, lds, st, a, *net, denoise_scale, do_denoise, x_out);
             if (traj && nstates > 0)
-                hipLaunchKernelGGL(rk45_traj_post_kernel, dim3(128), blk, 0, st, a.nrows, a.kcand, nstates, centre, traj);
+                hipLaunchKernelGGL(rk45_traj_post_kernel, dim3(128), blk1, 0, st, a.nrows, a.kcand, nstates, centre, traj);
             break;
         default:
             return GP_EINVAL;

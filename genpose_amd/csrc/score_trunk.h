@@ -9,39 +9,59 @@ namespace gp_trunk {
 constexpr int HID = 256, HEADS = 768, POSE = 9;
 
 // ---------------------------------------------------------------------------------------------- trunk
-// LDS layout for a P-row tile (floats):  X0 [P][16+8] | H1 [P][256+8] | H2 [P][256+8] | red [16][P][12]
+// Waves per workgroup.  Measured on MI355X at R = 3200 (16-row tiles, one workgroup per CU): 8 waves (two per SIMD) = 26.4 us
+// per sampler step vs 26.0 us with 4 - the phases are barrier-locked, so a second wave per SIMD has nothing different to
+// overlap with.  4 it is; build with -DGP_TRUNK_8W to re-measure.
+template <int P>
+struct TrunkCfg {
+#ifdef GP_TRUNK_8W
+    static constexpr int NW = (P <= 16) ? 8 : 4;
+#else
+    static constexpr int NW = 4;
+#endif
+    static constexpr int NV = 16 / NW;   // 16-channel chunks of a 256-wide layer per wave
+    static constexpr int NT = 64 * NW;   // threads per workgroup
+};
+
+// LDS layout for a P-row tile (floats):  X0 [P][16+8] | H1 [P][256+8] | H2 [P][256+8] | red [4*NW][P][12]
 template <int P>
 struct TrunkLds {
     static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD;
-    static constexpr int OFF_H1 = P * LD0, OFF_H2 = OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH, TOTAL = OFF_RED + 16 * P * 12;
+    static constexpr int OFF_H1 = P * LD0, OFF_H2 = OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH,
+                         TOTAL = OFF_RED + 4 * TrunkCfg<P>::NW * P * 12;
 };
 
-struct TrunkPre {
-    WStages<4> stA;  // first-layer weights (stages 0,1)
-    f32x4 b0[4];     // first-layer bias fragments
+template <int NV>
+struct TrunkPreT {
+    WStages<NV> stA;  // first-layer weights (stages 0,1)
+    f32x4 b0[NV];     // first-layer bias fragments
 };
+template <int P>
+using TrunkPre = TrunkPreT<TrunkCfg<P>::NV>;
 
 // Entry sequence shared by every kernel that evaluates the trunk: request the first layer's weights and bias
 // (call BEFORE any prologue work so the latency overlaps it).
 template <int P>
-__device__ __forceinline__ void trunk_begin(const gp_scorenet &net, TrunkPre &pre) {
+__device__ __forceinline__ void trunk_begin(const gp_scorenet &net, TrunkPre<P> &pre) {
+    constexpr int NW = TrunkCfg<P>::NW, NV = TrunkCfg<P>::NV;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ncl[4] = {wave, wave + 4, wave + 8, wave + 12};
-    mfma_preload<4>(pre.stA, net.w_pose0, 1, HID / 16, ncl);
+    const int ncl[4] = {wave, wave + NW, wave + 2 * NW, wave + 3 * NW};  // first NV entries are this wave's chunks
+    mfma_preload<NV>(pre.stA, net.w_pose0, 1, HID / 16, ncl);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pre.b0[i] = *reinterpret_cast<const f32x4 *>(net.b_pose0 + ncl[i] * 16 + 4 * (lane >> 4));
+    for (int i = 0; i < NV; ++i) pre.b0[i] = *reinterpret_cast<const f32x4 *>(net.b_pose0 + ncl[i] * 16 + 4 * (lane >> 4));
 }
 
 // dense 256-wide layer of the trunk on pre-requested weights and bias: out = relu(X W^T + b) -> LDS.
-template <int PT>
-__device__ __forceinline__ void trunk_dense(WStages<4> &st, const f32x4 (&bias)[4], const float *Xs, int ld, const float *__restrict__ Wp, int K,
-                                            float *Ys, int ldo) {
+template <int PT, int NW>
+__device__ __forceinline__ void trunk_dense(WStages<16 / NW> &st, const f32x4 (&bias)[16 / NW], const float *Xs, int ld,
+                                            const float *__restrict__ Wp, int K, float *Ys, int ldo) {
+    constexpr int NV = 16 / NW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nc[4] = {wave, wave + 4, wave + 8, wave + 12};
+    const int nc[4] = {wave, wave + NW, wave + 2 * NW, wave + 3 * NW};
     f32x4 acc[4][PT];
-    mfma_run<4, PT>(st, Xs, ld, 0, Wp, gp_round16(K) / 16, HID / 16, nc, acc);
+    mfma_run<NV, PT>(st, Xs, ld, 0, Wp, gp_round16(K) / 16, HID / 16, nc, acc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int ch = nc[i] * 16 + 4 * (lane >> 4);
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
@@ -56,17 +76,17 @@ __device__ __forceinline__ void trunk_dense(WStages<4> &st, const f32x4 (&bias)[
 }
 
 // epilogue operands of one head for this wave's four 16-channel chunks
-template <int PT>
+template <int PT, int NV>
 struct HeadOps {
-    f32x4 tv[4], w0[4], w1[4], w2[4], cv[4][PT];
+    f32x4 tv[NV], w0[NV], w1[NV], w2[NV], cv[NV][PT];
 };
 
-template <int PT>
-__device__ __forceinline__ void head_ops_load(HeadOps<PT> &o, const gp_scorenet &net, const float *__restrict__ cvec,
+template <int PT, int NV>
+__device__ __forceinline__ void head_ops_load(HeadOps<PT, NV> &o, const gp_scorenet &net, const float *__restrict__ cvec,
                                               const float *__restrict__ tvec, int h, const int (&nc)[4], const int (&cloud)[PT]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int ch = nc[i] * 16 + 4 * (lane >> 4);  // 0..767
         const int chh = ch - 256 * h;
         o.tv[i] = *reinterpret_cast<const f32x4 *>(tvec + ch);
@@ -83,17 +103,17 @@ __device__ __forceinline__ void head_ops_load(HeadOps<PT> &o, const gp_scorenet 
 // rows >= nrows are clamped duplicates.
 template <int P>
 __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net, const float *__restrict__ cvec, const float *__restrict__ tvec,
-                                             int row0, int nrows, int kcand, TrunkPre &pre) {
+                                             int row0, int nrows, int kcand, TrunkPre<P> &pre) {
     using L = TrunkLds<P>;
-    constexpr int PT = P / 16;
+    constexpr int PT = P / 16, NW = TrunkCfg<P>::NW, NV = TrunkCfg<P>::NV, NT = TrunkCfg<P>::NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *X0 = lds, *H1 = lds + L::OFF_H1, *H2 = lds + L::OFF_H2, *red = lds + L::OFF_RED;
-    const int ncl[4] = {wave, wave + 4, wave + 8, wave + 12};
+    const int ncl[4] = {wave, wave + NW, wave + 2 * NW, wave + 3 * NW};
     int nch[3][4];
 #pragma unroll
     for (int h = 0; h < 3; ++h)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) nch[h][i] = 16 * h + wave + 4 * i;  // head h owns n-chunks [16h, 16h+16)
+        for (int i = 0; i < 4; ++i) nch[h][i] = 16 * h + wave + NW * i;  // head h owns n-chunks [16h, 16h+16); first NV valid
     int cloud[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
@@ -103,18 +123,18 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
     }
     GP_T(2);
     // ---- layer 1 (9 -> 256); layer 2's first weight stages and bias are requested before it runs
-    WStages<4> stB;
-    f32x4 b2[4];
-    mfma_preload<4>(stB, net.w_pose2, HID / 16, HID / 16, ncl);
+    WStages<NV> stB;
+    f32x4 b2[NV];
+    mfma_preload<NV>(stB, net.w_pose2, HID / 16, HID / 16, ncl);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b2[i] = *reinterpret_cast<const f32x4 *>(net.b_pose2 + ncl[i] * 16 + 4 * (lane >> 4));
-    trunk_dense<PT>(pre.stA, pre.b0, X0, L::LD0, net.w_pose0, POSE, H1, L::LDH);
+    for (int i = 0; i < NV; ++i) b2[i] = *reinterpret_cast<const f32x4 *>(net.b_pose2 + ncl[i] * 16 + 4 * (lane >> 4));
+    trunk_dense<PT, NW>(pre.stA, pre.b0, X0, L::LD0, net.w_pose0, POSE, H1, L::LDH);
     __syncthreads();
     GP_T(3);
     // ---- layer 2 (256 -> 256); head 0's weights (and, small tile, its epilogue operands) requested before it runs
-    WStages<4> stH[2];
-    mfma_preload<4>(stH[0], net.w_headx, HID / 16, HEADS / 16, nch[0]);
-    trunk_dense<PT>(stB, b2, H1, L::LDH, net.w_pose2, HID, H2, L::LDH);
+    WStages<NV> stH[2];
+    mfma_preload<NV>(stH[0], net.w_headx, HID / 16, HEADS / 16, nch[0]);
+    trunk_dense<PT, NW>(stB, b2, H1, L::LDH, net.w_pose2, HID, H2, L::LDH);
     GP_T(4);
     __syncthreads();
     GP_T(5);
@@ -126,16 +146,16 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         // next head's first weight stages are requested before this head runs (hides the cold start).  The epilogue
         // operands are NOT hoisted above the MFMA loop: measured slower (their ~20 KB/wave of broadcast loads queue
         // in front of the loop's counted weight prefetches).
-        if (h < 2) mfma_preload<4>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
-        mfma_run<4, PT>(stH[h & 1], H2, L::LDH, 0, net.w_headx, HID / 16, HEADS / 16, nch[h], acc);
+        if (h < 2) mfma_preload<NV>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
+        mfma_run<NV, PT>(stH[h & 1], H2, L::LDH, 0, net.w_headx, HID / 16, HEADS / 16, nch[h], acc);
         GP_T(7 + 3 * h);
-        HeadOps<PT> o;
-        head_ops_load<PT>(o, net, cvec, tvec, h, nch[h], cloud);
+        HeadOps<PT, NV> o;
+        head_ops_load<PT, NV>(o, net, cvec, tvec, h, nch[h], cloud);
         float part[PT][3];  // [p-chunk][component], this wave's n-chunks of head h
 #pragma unroll
         for (int p = 0; p < PT; ++p) part[p][0] = part[p][1] = part[p][2] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NV; ++i) {
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
                 f32x4 v = acc[i][p] + o.cv[i][p] + o.tv[i];
@@ -156,11 +176,11 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         GP_T(8 + 3 * h);
     }
     __syncthreads();
-    for (int e = tid; e < P * POSE; e += 256) {
+    for (int e = tid; e < P * POSE; e += NT) {
         const int r = e / POSE, j = e - r * POSE;
         float v = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v += red[(q * P + r) * 12 + j];
+        for (int q = 0; q < 4 * NW; ++q) v += red[(q * P + r) * 12 + j];
         H1[r * L::LDH + j] = v + net.b_out[j];  // parked in H1 (free now)
     }
     __syncthreads();
@@ -169,7 +189,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
 template <int P>
 __device__ __forceinline__ void load_x_tile(float *lds, const float *__restrict__ x, int row0, int nrows) {
     using L = TrunkLds<P>;
-    for (int e = threadIdx.x; e < P * 16; e += 256) {
+    for (int e = threadIdx.x; e < P * 16; e += TrunkCfg<P>::NT) {
         const int r = e >> 4, j = e & 15;
         int g = row0 + r;
         if (g >= nrows) g = nrows - 1;

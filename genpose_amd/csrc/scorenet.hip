@@ -70,13 +70,13 @@ __global__ __launch_bounds__(256) void time_embed_kernel(gp_scorenet net, const 
 
 // mode 0: score = f/(sigma+1e-7)  (scorenet.py:217);  mode 1: IP energy with s = f/sigma (energynet.py:163-185)
 template <int P>
-__global__ __launch_bounds__(256, 2) void score_eval_kernel(int nrows, int kcand, gp_scorenet net, const float *__restrict__ cvec,
+__global__ __launch_bounds__(TrunkCfg<P>::NT) void score_eval_kernel(int nrows, int kcand, gp_scorenet net, const float *__restrict__ cvec,
                                                          const float *__restrict__ tvec, const float *__restrict__ x,
                                                          const float *__restrict__ sigma_dev, int mode, float *__restrict__ out) {
     using L = TrunkLds<P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int row0 = blockIdx.x * P, tid = threadIdx.x;
-    TrunkPre pre;
+    TrunkPre<P> pre;
     trunk_begin<P>(net, pre);
     load_x_tile<P>(lds, x, row0, nrows);
     __syncthreads();
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void score_eval_kernel(int nrows, int kcand
     const float sigma = *sigma_dev;
     const float *F = lds + L::OFF_H1;
     if (mode == 0) {
-        for (int e = tid; e < P * POSE; e += 256) {
+        for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
             const int r = e / POSE, j = e - r * POSE;
             if (row0 + r < nrows) out[(size_t)(row0 + r) * POSE + j] = F[r * L::LDH + j] / (sigma + 1e-7f);
         }
@@ -119,13 +119,13 @@ struct PcArgs {
 //   i < nsteps : evaluate score_i = s(x_i, t_i) and write this block's partial sum of |score_i|_2
 //   i == nsteps: (finish only) also post-process mean_x (:157-158)
 template <int P>
-__global__ __launch_bounds__(256, 2) void pc_step_kernel(PcArgs a, gp_scorenet net) {
+__global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_scorenet net) {
     using L = TrunkLds<P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_gn;
     const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
     if (i < a.nsteps) GP_T(0);
-    TrunkPre pre;
+    TrunkPre<P> pre;
     if (i < a.nsteps) trunk_begin<P>(net, pre);
     if (i > 0) {
         // (1) row threads request their operands first; (2) meanwhile the last wave reduces the per-block partial sums
@@ -148,12 +148,13 @@ __global__ __launch_bounds__(256, 2) void pc_step_kernel(PcArgs a, gp_scorenet n
             const float *cp = a.centre + (size_t)(r / a.kcand) * 3;
             cen[0] = cp[0], cen[1] = cp[1], cen[2] = cp[2];
         }
-        if (tid >= 192) {
+        constexpr int LASTW = TrunkCfg<P>::NT - 64;
+        if (tid >= LASTW) {
             float s = 0.f;
             const float *pp = a.partials + (size_t)(i - 1) * a.nblocks;
-            for (int q = tid - 192; q < a.nblocks; q += 64) s += pp[q];
+            for (int q = tid - LASTW; q < a.nblocks; q += 64) s += pp[q];
             s = wave_sum_f32(s);
-            if (tid == 192) s_gn = s / (float)a.nrows;
+            if (tid == LASTW) s_gn = s / (float)a.nrows;
         }
         __syncthreads();
         if (i < a.nsteps) GP_T(20);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void pc_step_kernel(PcArgs a, gp_scorenet n
     GP_T(16);
     const float sigma = a.sched[(size_t)i * 4 + 0];
     float *F = lds + L::OFF_H1;
-    for (int e = tid; e < P * POSE; e += 256) {
+    for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
         const int r = e / POSE, j = e - r * POSE;
         const float v = F[r * L::LDH + j] / (sigma + 1e-7f);
         F[r * L::LDH + j] = v;
@@ -282,10 +283,10 @@ int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec,
         attr_done = true;
     }
     if (P == 16)
-        hipLaunchKernelGGL(score_eval_kernel<16>, dim3((R + 15) / 16), dim3(256), trunk_lds_bytes<16>(), (hipStream_t)s, R, k, *net, cvec, tvec,
+        hipLaunchKernelGGL(score_eval_kernel<16>, dim3((R + 15) / 16), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), (hipStream_t)s, R, k, *net, cvec, tvec,
                            x, sigma_dev, mode, out);
     else
-        hipLaunchKernelGGL(score_eval_kernel<32>, dim3((R + 31) / 32), dim3(256), trunk_lds_bytes<32>(), (hipStream_t)s, R, k, *net, cvec, tvec,
+        hipLaunchKernelGGL(score_eval_kernel<32>, dim3((R + 31) / 32), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), (hipStream_t)s, R, k, *net, cvec, tvec,
                            x, sigma_dev, mode, out);
     return gp_launch_status();
 }
@@ -313,9 +314,9 @@ int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net,
         attr_done = true;
     }
     if (P == 16)
-        hipLaunchKernelGGL(pc_step_kernel<16>, dim3(a.nblocks), dim3(256), trunk_lds_bytes<16>(), (hipStream_t)s, a, *net);
+        hipLaunchKernelGGL(pc_step_kernel<16>, dim3(a.nblocks), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), (hipStream_t)s, a, *net);
     else
-        hipLaunchKernelGGL(pc_step_kernel<32>, dim3(a.nblocks), dim3(256), trunk_lds_bytes<32>(), (hipStream_t)s, a, *net);
+        hipLaunchKernelGGL(pc_step_kernel<32>, dim3(a.nblocks), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), (hipStream_t)s, a, *net);
     return gp_launch_status();
 }
 
