@@ -51,9 +51,14 @@ __host__ __device__ static inline int gp_round16(int v) { return (v + 15) & ~15;
 // register rotation copies are needed, and sched_barrier keeps the requests ABOVE the MFMA block (hipcc otherwise
 // sinks loads next to their first use and the counted s_waitcnt degenerates to vmcnt(0)).
 // mfma_preload() may be issued EARLY (before the producing layer's epilogue / barrier) to hide the cold start.
+#ifndef GP_MFMA_STAGES
+#define GP_MFMA_STAGES 3  // register stages of the weight/activation pipeline (prefetch distance = stages - 1 k-groups)
+#endif
+constexpr int MST = GP_MFMA_STAGES;
+
 template <int NV>
 struct WStages {
-    f32x4 w[3][NV];
+    f32x4 w[MST][NV];
 };
 
 template <int NV>
@@ -61,7 +66,7 @@ __device__ __forceinline__ void mfma_preload(WStages<NV> &st, const float *__res
     const int lane = threadIdx.x & 63;
     const size_t kstride = (size_t)NC * 64;
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < MST - 1; ++d) {
         const int k0 = d < KG ? d : KG - 1;
 #pragma unroll
         for (int i = 0; i < NV; ++i) st.w[d][i] = (reinterpret_cast<const f32x4 *>(Wp) + (size_t)nc[i] * 64 + lane)[(size_t)k0 * kstride];
@@ -83,9 +88,9 @@ __device__ __forceinline__ void mfma_run(WStages<NV> &st, const float *Xs, int l
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int p = 0; p < PT; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 xq[3][PT];
+    f32x4 xq[MST][PT];
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < MST - 1; ++d) {
         const int k0 = d < KG ? d : KG - 1;
 #pragma unroll
         for (int p = 0; p < PT; ++p) xq[d][p] = *reinterpret_cast<const f32x4 *>(xrow[p] + k0 * 16);
@@ -94,11 +99,11 @@ __device__ __forceinline__ void mfma_run(WStages<NV> &st, const float *Xs, int l
     // k-group, harmless) so that the compiler's s_waitcnt counts stay exact: vmcnt(2*NV) = "two stages still in flight"
     int kg = 0;
 #pragma unroll 1
-    for (; kg + 3 <= KG; kg += 3) {
+    for (; kg + MST <= KG; kg += MST) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int nxt = (kg + d + 2 < KG) ? kg + d + 2 : KG - 1;
-            const int e = (d + 2) % 3;
+        for (int d = 0; d < MST; ++d) {
+            const int nxt = (kg + d + MST - 1 < KG) ? kg + d + MST - 1 : KG - 1;
+            const int e = (d + MST - 1) % MST;
 #ifndef GP_EXP_NOWLOAD
 #pragma unroll
             for (int i = 0; i < NV; ++i) st.w[e][i] = wp[i][(size_t)nxt * kstride];
@@ -116,9 +121,9 @@ __device__ __forceinline__ void mfma_run(WStages<NV> &st, const float *Xs, int l
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // tail: KG % 3 k-groups, already resident in stages 0 (and 1)
+    // tail: KG % MST k-groups, already resident in stages 0 .. MST-2
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < MST - 1; ++d) {
         if (kg + d < KG) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
