@@ -1,0 +1,72 @@
+"""GPU: the three implementations of a grouping set-abstraction scale agree - tile kernel on the un-hoisted form
+(gp_sa_mlp_max), tile kernel on the hoisted form (gp_sa_pre_mlp_max with GP_SA_NOCHAIN semantics is not selectable at run time,
+so the hoisted entry point is compared as dispatched: register-chain kernels for the light config) - and match the oracle's
+grouped conv+BN+ReLU+max."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import genpose_oracle as go
+from oracle import pn2_oracle as ops
+
+
+@pytest.mark.parametrize("level,scale", [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1)])
+def test_sa_scale_paths_agree(level, scale):
+    from genpose_amd import _lib, synth
+    from genpose_amd._lib import ptr, stream_ptr
+    from genpose_amd.weights import EncoderWeights
+    sd = go.make_state_dict(0, "score")
+    B = 3
+    pts = torch.from_numpy(synth.make_batch(B, start=70))
+    _, inter = go.encoder_forward(sd, pts, return_intermediates=True)
+    cfg = go.LIGHT_CFG
+    # inputs of this level from the oracle's intermediates
+    xyz = pts.numpy() if level == 0 else inter[level - 1]["new_xyz"]
+    feats = None if level == 0 else np.ascontiguousarray(inter[level - 1]["features"].transpose(0, 2, 1))  # [B,n,C]
+    new_xyz = inter[level]["new_xyz"]
+    bq = inter[level][f"bq_idx{scale}"]
+    n, npnt, ns = xyz.shape[1], new_xyz.shape[1], bq.shape[2]
+    spec = cfg["mlps"][level][scale]
+    cout_all = sum(m[-1] for m in cfg["mlps"][level])
+    off = sum(m[-1] for m in cfg["mlps"][level][:scale])
+    ref = inter[level]["features"][:, off:off + spec[-1], :].transpose(0, 2, 1)  # [B,np,c3]
+
+    ew = EncoderWeights(sd, "cuda")
+    sc = ew.levels[level][scale]
+    (w1, b1), (w2, b2), (w3, b3) = sc.layers
+    d = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+    xyz_d, nx_d, bq_d = d(xyz), d(new_xyz), d(bq, torch.int32)
+    f_d = None if feats is None else d(feats)
+    cin = 0 if feats is None else feats.shape[2]
+    st = stream_ptr()
+    out_a = torch.zeros(B, npnt, cout_all, device="cuda")
+    _lib.call("gp_sa_mlp_max", B, n, npnt, ns, cin, spec[0], spec[1], spec[2], ptr(xyz_d), ptr(f_d), ptr(nx_d), ptr(bq_d), ptr(w1), ptr(b1),
+              ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out_a), cout_all, off, st)
+    out_b = torch.zeros(B, npnt, cout_all, device="cuda")
+    z, zstride, zoff = None, 0, 0
+    if cin:
+        zstride = sum(s_.couts[0] for s_ in ew.levels[level])
+        zoff = sum(s_.couts[0] for s_ in ew.levels[level][:scale])
+        z = torch.empty(B, n, zstride, device="cuda")
+        _lib.call("gp_point_linear", B * n, cin, zstride, ptr(f_d), ptr(ew.z_weights[level]), ptr(z), st)
+    _lib.call("gp_sa_pre_mlp_max", B, n, npnt, ns, spec[0], spec[1], spec[2], ptr(xyz_d), ptr(nx_d), ptr(bq_d), ptr(z), zstride, zoff,
+              ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out_b), cout_all, off, st)
+    a = out_a[:, :, off:off + spec[-1]].cpu().numpy()
+    b = out_b[:, :, off:off + spec[-1]].cpu().numpy()
+    np.testing.assert_allclose(a, ref, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(b, ref, rtol=2e-4, atol=2e-4)
+    assert np.all(out_a[:, :, :off].cpu().numpy() == 0) and np.all(out_b[:, :, off + spec[-1]:].cpu().numpy() == 0)  # writes only its slice
+
+
+def test_unsupported_shapes_fail_loudly():
+    from genpose_amd import _lib
+    from genpose_amd._lib import ptr, stream_ptr
+    x = torch.zeros(1, 64, 3, device="cuda")
+    idx = torch.zeros(1, 8, 8, dtype=torch.int32, device="cuda")
+    w = torch.zeros(4096, device="cuda")
+    out = torch.zeros(1, 8, 32, device="cuda")
+    with pytest.raises(_lib.GenposeHipError):  # nsample 8 (the reference's 'dense' config, level 2) is not a multiple of 16
+        _lib.call("gp_sa_mlp_max", 1, 64, 8, 8, 0, 16, 16, 32, ptr(x), None, ptr(x), ptr(idx), ptr(w), ptr(w), ptr(w), ptr(w), ptr(w), ptr(w),
+                  ptr(out), 32, 0, stream_ptr())
