@@ -161,6 +161,18 @@ def main():
         roofline = {"bound": "mfma", "kernel": f"pc_step_kernel<{gp_lib.lib().gp_score_tile_rows(B * K)}>", "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "avg_launch_us": round(per_launch_s * 1e6, 2), "flops_per_launch": flops_per_launch}
+        # HBM-side bytes per launch come from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in separate
+        # rocprofv3 runs, gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); only valid for the profiled shape
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if B * K == 3200 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))[roofline["kernel"]]
+                roofline["traffic"] = tj["corrected_bytes_per_launch"]
+                roofline["traffic_note"] = (f"PMC, profiles/r1_pmc_traffic.json: raw {tj['raw_bytes_per_launch']} B, algorithmic "
+                                            f"{tj['algorithmic_bytes_per_launch']} B; Infinity-Cache hits are counted (the 1 MB weight set "
+                                            "is re-fetched by each of the 8 XCD L2s every launch)")
+            except (KeyError, ValueError):
+                pass
         in_situ = pipe.sampler_launch_seconds() if pipe is not None else None
         if in_situ:
             roofline["in_situ_avg_launch_us"] = round(in_situ * 1e6, 2)
