@@ -563,6 +563,187 @@ int launch_chain_lds(const SAPreArgs &a, int b, hipStream_t st) {
     return gp_launch_status();
 }
 
+// Chain kernel for a level whose layer-3 weights do not fit LDS (light config level 2: 128 -> 196 -> 256):
+//   * 8 waves per workgroup, each wave walks its own neighbourhoods 16 rows at a time, activations in registers;
+//   * layer-2 weights (Q1*Q2 KB) are LDS-resident; layer-3 weights stream through a 3-slot LDS ring, one k-group slice
+//     (Q3 KB) per step, shared by all 8 waves: slice g+2 is written while slice g is multiplied, ONE barrier per step;
+//   * every wave runs the same number of iterations (idle ones compute on clamped rows and store nothing) so the
+//     barriers line up.
+// L2 traffic per 128 rows: one sweep of the layer-3 weights (208 KB) instead of one sweep of both layers per 32 rows.
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int ncentres_total) {
+    constexpr int PT = NS / 16, Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16, NWV = 8, NTH = 512;
+    static_assert(Q3 % 4 == 0 && (Q3 * 64) % NTH == 0, "layer-3 slice must split evenly over the workgroup");
+    constexpr int SLICE = Q3 * 64;          // f32x4 per k-group slice of layer 3
+    constexpr int PER_T = SLICE / NTH;      // f32x4 each thread moves per slice
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4 *w2l = reinterpret_cast<f32x4 *>(lds);   // [Q1][Q2][64] resident
+    f32x4 *ring = w2l + Q1 * Q2 * 64;               // [3][Q3][64]
+    f32x4 *w1l = ring + 3 * SLICE;                  // [C1] rows (wx, wy, wz, b1)
+    const int tid = threadIdx.x, lane = tid & 63, pt = lane & 15, g = lane >> 4;
+    for (int e = tid; e < Q1 * Q2 * 64; e += NTH) w2l[e] = reinterpret_cast<const f32x4 *>(a.w2)[e];
+    for (int e = tid; e < C1; e += NTH) {
+        f32x4 w = *reinterpret_cast<const f32x4 *>(a.wxyz + e * 4);
+        w.w = a.b1[e];
+        w1l[e] = w;
+    }
+    const f32x4 *w3g = reinterpret_cast<const f32x4 *>(a.w3);  // [Q2][Q3][64]: slice q = w3g + q*SLICE
+    // ring prologue: slices 0 and 1 into slots 0 and 1; slice 2 held in registers
+    f32x4 hold[PER_T];
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+        ring[0 * SLICE + tid + u * NTH] = w3g[0 * SLICE + tid + u * NTH];
+        ring[1 * SLICE + tid + u * NTH] = w3g[(1 % Q2) * SLICE + tid + u * NTH];
+        hold[u] = w3g[(2 % Q2) * SLICE + tid + u * NTH];
+    }
+    __syncthreads();
+    const int wave_global = blockIdx.x * NWV + (tid >> 6), nwaves = gridDim.x * NWV;
+    const int my_centres = wave_global < ncentres_total ? (ncentres_total - wave_global + nwaves - 1) / nwaves : 0;
+    const int nits = my_centres * PT;
+    const int nits_wg = ((ncentres_total + nwaves - 1) / nwaves) * PT;  // uniform over the grid: barrier counts match
+    auto chunk_row0 = [&](int it, int &c) {
+        c = wave_global + (it / PT) * nwaves;
+        return (size_t)c * NS + (size_t)(it % PT) * 16;
+    };
+    auto load_idx = [&](int it) {
+        int c;
+        const size_t r0 = chunk_row0(it, c);
+        return it < nits ? a.idx[r0 + pt] : 0;
+    };
+    auto load_ops = [&](int it, int j, float (&d)[3], f32x4 (&zz)[Q1]) {
+        int c;
+        chunk_row0(it, c);
+        const int cc = it < nits ? c : 0;
+        const int bcl = cc / a.np;
+        const float *xyz = a.xyz + (size_t)bcl * a.n * 3;
+        const float *zb = a.z + (size_t)bcl * a.n * a.zstride + a.zoff;
+        const float *cp = a.new_xyz + (size_t)cc * 3;
+        d[0] = xyz[j * 3 + 0] - cp[0];  // grouped_xyz -= new_xyz (pointnet2_utils.py:253)
+        d[1] = xyz[j * 3 + 1] - cp[1];
+        d[2] = xyz[j * 3 + 2] - cp[2];
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) zz[q] = *reinterpret_cast<const f32x4 *>(zb + (size_t)j * a.zstride + 16 * q + 4 * g);
+    };
+    // register budget (256 at two waves per SIMD): the operands of the NEXT chunk are requested into the same registers
+    // right after layer 1 has consumed the current ones (the ~40 k cycles of layers 2-3 cover the latency); biases are
+    // re-read from L1/L2 where they are used; the running max of a two-chunk neighbourhood round-trips through `out`.
+    int jn;
+    float dcur[3];
+    f32x4 zcur[Q1];
+    jn = load_idx(0);
+    load_ops(0, jn, dcur, zcur);
+    jn = load_idx(1);
+    int gstep = 0;  // global ring step: slice gstep % Q2 sits in slot gstep % 3
+#pragma unroll 1
+    for (int it = 0; it < nits_wg; ++it) {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));  // keep the LDS weight reads inside the loop (see sa_chain_lds_kernel)
+        const int p = it % PT;
+        const float dx = dcur[0], dy = dcur[1], dz = dcur[2];
+        f32x4 h1[Q1], h2[Q2];
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) {
+            const int g4 = (lo >> 4) * 4;
+            const f32x4 r0 = w1l[16 * q + g4 + 0], r1 = w1l[16 * q + g4 + 1], r2 = w1l[16 * q + g4 + 2], r3 = w1l[16 * q + g4 + 3];
+            f32x4 v = zcur[q];
+            v.x += (r0.x * dx + r0.y * dy + r0.z * dz) + r0.w;
+            v.y += (r1.x * dx + r1.y * dy + r1.z * dz) + r1.w;
+            v.z += (r2.x * dx + r2.y * dy + r2.z * dz) + r2.w;
+            v.w += (r3.x * dx + r3.y * dy + r3.z * dz) + r3.w;
+            h1[q] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+        }
+        load_ops(it + 1, jn, dcur, zcur);
+        jn = load_idx(it + 2);
+        // ---- layer 2 from the resident weights, two output chunks in flight
+#pragma unroll
+        for (int n0 = 0; n0 < Q2; n0 += 2) {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) {
+                f32x4 wf[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) wf[u] = (n0 + u < Q2) ? w2l[(q * Q2 + n0 + u) * 64 + lo] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (n0 + u < Q2) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h1[q][jj], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (n0 + u < Q2) {
+                    f32x4 v = acc[u] + *reinterpret_cast<const f32x4 *>(a.b2 + 16 * (n0 + u) + 4 * (lo >> 4));
+                    h2[n0 + u] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                }
+        }
+        // ---- layer 3 through the ring: Q2 steps, all Q3 output chunks accumulate across the steps
+        f32x4 acc3[Q3];
+#pragma unroll
+        for (int n = 0; n < Q3; ++n) acc3[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < Q2; ++q) {
+            // slice gstep+2 (held in registers since the previous step) -> its slot, which was last read in step gstep-1
+            {
+                f32x4 *dst = ring + ((gstep + 2) % 3) * SLICE;
+#pragma unroll
+                for (int u = 0; u < PER_T; ++u) dst[tid + u * NTH] = hold[u];
+                const f32x4 *src = w3g + ((gstep + 3) % Q2) * SLICE;
+#pragma unroll
+                for (int u = 0; u < PER_T; ++u) hold[u] = src[tid + u * NTH];
+            }
+            const f32x4 *slot = ring + (gstep % 3) * SLICE;
+#pragma unroll
+            for (int n0 = 0; n0 < Q3; n0 += 4) {
+                f32x4 wf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wf[u] = slot[(n0 + u) * 64 + lo];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc3[n0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h2[q][jj], acc3[n0 + u], 0, 0, 0);
+            }
+            ++gstep;
+            __syncthreads();
+        }
+        {
+            const int c = wave_global + (it / PT) * nwaves;
+            float *o = a.out + (size_t)(it < nits ? c : 0) * a.cout_total + a.cout_off;
+#pragma unroll
+            for (int n = 0; n < Q3; ++n) {
+                const f32x4 v = acc3[n] + *reinterpret_cast<const f32x4 *>(a.b3 + 16 * n + 4 * (lo >> 4));
+                f32x4 m = {row16_max(fmaxf(v.x, 0.f)), row16_max(fmaxf(v.y, 0.f)), row16_max(fmaxf(v.z, 0.f)), row16_max(fmaxf(v.w, 0.f))};
+                if (pt == 0 && it < nits) {
+                    f32x4 *op = reinterpret_cast<f32x4 *>(o + 16 * n + 4 * g);
+                    if (p > 0) {  // later chunk of the same neighbourhood: combine with what this lane stored for the earlier one
+                        const f32x4 prev = *op;
+                        m = f32x4{fmaxf(m.x, prev.x), fmaxf(m.y, prev.y), fmaxf(m.z, prev.z), fmaxf(m.w, prev.w)};
+                    }
+                    *op = m;
+                }
+            }
+        }
+    }
+}
+
+template <int C1, int C2, int C3, int NS>
+int launch_chain_ring(const SAPreArgs &a, int b, hipStream_t st) {
+    constexpr int Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16;
+    const size_t lds = ((size_t)(Q1 * Q2 + 3 * Q3) * 64 + C1) * sizeof(f32x4);
+    if (lds > 160 * 1024) return GP_EINVAL;
+    auto kern = sa_chain_ring_kernel<C1, C2, C3, NS>;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GP_ELAUNCH;
+        done = true;
+    }
+    const int ncentres = b * a.np;
+    int blocks = (ncentres + 7) / 8;
+    if (blocks > 256) blocks = 256;  // persistent, one 8-wave workgroup per CU (154 KB LDS)
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, a, ncentres);
+    return gp_launch_status();
+}
+
 template <int C1, int C2, int C3, int NS>
 int launch_chain(const SAPreArgs &a, int b, hipStream_t st) {
     const int ncentres = b * a.np;
@@ -664,6 +845,10 @@ int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, cons
     if (z && !nochain && (zoff % 4) == 0 && (zstride % 4) == 0) {
         if (c1 == 64 && c2 == 64 && c3 == 128 && ns == 16) return launch_chain_lds<64, 64, 128, 16>(a, b, (hipStream_t)s);
         if (c1 == 64 && c2 == 96 && c3 == 128 && ns == 32) return launch_chain_lds<64, 96, 128, 32>(a, b, (hipStream_t)s);
+        static int noring = -1;
+        if (noring < 0) noring = getenv("GP_SA_NORING") ? 1 : 0;
+        if (!noring && c1 == 128 && c2 == 196 && c3 == 256 && ns == 16) return launch_chain_ring<128, 196, 256, 16>(a, b, (hipStream_t)s);
+        if (!noring && c1 == 128 && c2 == 196 && c3 == 256 && ns == 32) return launch_chain_ring<128, 196, 256, 32>(a, b, (hipStream_t)s);
     }
     const bool narrow = c1 <= 64 && c2 <= 64 && c3 <= 64;
     if (ns <= 32 && !narrow) return launch_pre<32>(a, b, (hipStream_t)s);
