@@ -556,7 +556,12 @@ int launch_chain_lds(const SAPreArgs &a, int b, hipStream_t st) {
         done = true;
     }
     const int ncentres = b * a.np;
-    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;
+    static int forced_pc = -1;  // GP_SA_CHAIN_PER_CU = 1 | 2 (tuning)
+    if (forced_pc < 0) {
+        const char *e = getenv("GP_SA_CHAIN_PER_CU");
+        forced_pc = e ? atoi(e) : 0;
+    }
+    const int per_cu = forced_pc > 0 ? forced_pc : ((int)((160 * 1024) / lds) < 2 ? 1 : 2);
     int blocks = (ncentres + 3) / 4;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // persistent: weights are staged once per workgroup
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a, ncentres);
