@@ -9,16 +9,31 @@ static inline int gp_launch_status() { return hipGetLastError() == hipSuccess ? 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Keeps an early-requested value where it was requested: without it hipcc sinks the load next to its first use.
+__device__ __forceinline__ void gp_pin(float &v) { asm volatile("" : "+v"(v)); }
+
 // Phase timestamps for tuning builds (python -m genpose_amd.build with GP_TIMING=1): block 0, lane 0 of every wave.
+// The stamps stay in registers (struct GpStamps, carried in the trunk's TrunkPre) and are written out once at the end
+// of the kernel: a store per stamp would put an s_waitcnt lgkmcnt(0) - i.e. a drain of all LDS traffic - at every phase edge.
 #ifdef GP_TIMING
 extern __device__ unsigned long long gp_dbg_ts[4 * 32];
-#define GP_T(i)                                                                                          \
-    do {                                                                                                 \
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) gp_dbg_ts[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+struct GpStamps {
+    unsigned long long t[24];
+};
+#define GP_T(i) (pre.ts.t[(i)] = __builtin_amdgcn_s_memtime())
+#define GP_T_FLUSH()                                                                          \
+    do {                                                                                      \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                     \
+            _Pragma("unroll") for (int q_ = 0; q_ < 24; ++q_) gp_dbg_ts[(threadIdx.x >> 6) * 32 + q_] = pre.ts.t[q_]; \
+        }                                                                                     \
     } while (0)
 #else
+struct GpStamps {};
 #define GP_T(i) \
     do {        \
+    } while (0)
+#define GP_T_FLUSH() \
+    do {             \
     } while (0)
 #endif
 
@@ -73,9 +88,50 @@ __device__ __forceinline__ void mfma_preload(WStages<NV> &st, const float *__res
     }
 }
 
+struct MfmaNoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// One pipeline step: request stage (d + MST - 1) % MST for k-group kgd + MST - 1 (clamped), multiply stage d.
+template <int NV, int PT, int D>
+__device__ __forceinline__ void mfma_step(WStages<NV> &st, f32x4 (&xq)[MST][PT], const f32x4 *const (&wp)[NV], const float *const (&xrow)[PT],
+                                          size_t kstride, int kgd, int KG, f32x4 (&acc)[4][PT]) {
+    const int nxt = (kgd + MST - 1 < KG) ? kgd + MST - 1 : KG - 1;
+    constexpr int e = (D + MST - 1) % MST;
+#ifndef GP_EXP_NOWLOAD
+#pragma unroll
+    for (int i = 0; i < NV; ++i) st.w[e][i] = wp[i][(size_t)nxt * kstride];
+#endif
+#pragma unroll
+    for (int p = 0; p < PT; ++p) xq[e][p] = *reinterpret_cast<const f32x4 *>(xrow[p] + nxt * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.w[D][i][jj], xq[D][p][jj], acc[i][p], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int NV, int PT>
+__device__ __forceinline__ void mfma_triple(WStages<NV> &st, f32x4 (&xq)[MST][PT], const f32x4 *const (&wp)[NV], const float *const (&xrow)[PT],
+                                            size_t kstride, int kg, int KG, f32x4 (&acc)[4][PT]) {
+    static_assert(MST >= 2 && MST <= 5, "stage count");
+    mfma_step<NV, PT, 0>(st, xq, wp, xrow, kstride, kg, KG, acc);
+    mfma_step<NV, PT, 1>(st, xq, wp, xrow, kstride, kg + 1, KG, acc);
+    if constexpr (MST > 2) mfma_step<NV, PT, 2>(st, xq, wp, xrow, kstride, kg + 2, KG, acc);
+    if constexpr (MST > 3) mfma_step<NV, PT, 3>(st, xq, wp, xrow, kstride, kg + 3, KG, acc);
+    if constexpr (MST > 4) mfma_step<NV, PT, 4>(st, xq, wp, xrow, kstride, kg + 4, KG, acc);
+}
+
+// `mid` (optional) is invoked once after the k-groups below `kmid` (rounded down to whole stage rounds): loads issued there
+// (an epilogue's operands) travel in the shadow of the remaining MFMAs.  The round that follows it is straight-line code, so
+// the compiler's counted s_waitcnt stays exact across the extra requests (a loop header would merge to the conservative count
+// and stall on them at once).
+template <int NV, int PT, class Mid = MfmaNoMid>
 __device__ __forceinline__ void mfma_run(WStages<NV> &st, const float *Xs, int ld, int pc0, const float *__restrict__ Wp, int KG, int NC,
-                                         const int (&nc)[4], f32x4 (&acc)[4][PT]) {
+                                         const int (&nc)[4], f32x4 (&acc)[4][PT], Mid mid = Mid(), int kmid = 0) {
     const int lane = threadIdx.x & 63;
     const float *xrow[PT];
 #pragma unroll
@@ -95,32 +151,21 @@ __device__ __forceinline__ void mfma_run(WStages<NV> &st, const float *Xs, int l
 #pragma unroll
         for (int p = 0; p < PT; ++p) xq[d][p] = *reinterpret_cast<const f32x4 *>(xrow[p] + k0 * 16);
     }
-    // main loop: whole triples, branch-free body (clamped prefetch index: the last two requests re-read the final
+    // main loop: whole stage rounds, branch-free body (clamped prefetch index: the last requests re-read the final
     // k-group, harmless) so that the compiler's s_waitcnt counts stay exact: vmcnt(2*NV) = "two stages still in flight"
     int kg = 0;
+    if constexpr (!__is_same(Mid, MfmaNoMid)) {
 #pragma unroll 1
-    for (; kg + MST <= KG; kg += MST) {
-#pragma unroll
-        for (int d = 0; d < MST; ++d) {
-            const int nxt = (kg + d + MST - 1 < KG) ? kg + d + MST - 1 : KG - 1;
-            const int e = (d + MST - 1) % MST;
-#ifndef GP_EXP_NOWLOAD
-#pragma unroll
-            for (int i = 0; i < NV; ++i) st.w[e][i] = wp[i][(size_t)nxt * kstride];
-#endif
-#pragma unroll
-            for (int p = 0; p < PT; ++p) xq[e][p] = *reinterpret_cast<const f32x4 *>(xrow[p] + nxt * 16);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int i = 0; i < NV; ++i)
-#pragma unroll
-                    for (int p = 0; p < PT; ++p)
-                        acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.w[d][i][jj], xq[d][p][jj], acc[i][p], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (; kg + MST <= kmid && kg + MST <= KG; kg += MST) mfma_triple<NV, PT>(st, xq, wp, xrow, kstride, kg, KG, acc);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kg + MST <= KG) {
+            mfma_triple<NV, PT>(st, xq, wp, xrow, kstride, kg, KG, acc);
+            kg += MST;
         }
     }
+#pragma unroll 1
+    for (; kg + MST <= KG; kg += MST) mfma_triple<NV, PT>(st, xq, wp, xrow, kstride, kg, KG, acc);
     // tail: KG % MST k-groups, already resident in stages 0 .. MST-2
 #pragma unroll
     for (int d = 0; d < MST - 1; ++d) {

@@ -100,8 +100,10 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
     const size_t n = (size_t)a.nrows * 9;
     const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
     TrunkPre<P> pre;
-    trunk_begin<P>(net, pre);
+    trunk_begin<P>(net, pre, a.cvec, a.tvec + (size_t)slot * HEADS, row0, a.nrows, a.kcand);
     const double h = st->h;
+    const float sigma = st->stage_sigma[slot];  // requested now, used after the trunk
+    const double g2 = st->stage_g2[slot];
     if (tid < P) {
         const bool live = row0 + tid < a.nrows;
         const int r = live ? row0 + tid : a.nrows - 1;
@@ -144,8 +146,6 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
     }
     __syncthreads();
     trunk_ftheta<P>(lds, net, a.cvec, a.tvec + (size_t)slot * HEADS, row0, a.nrows, a.kcand, pre);
-    const float sigma = st->stage_sigma[slot];
-    const double g2 = st->stage_g2[slot];
     const float *F = lds + L::OFF_H1;
     double *Kout = a.K + (size_t)(STAGE == 7 ? 1 : (STAGE == 0 ? 0 : (STAGE == 6 ? 6 : STAGE))) * n;
     double acc0 = 0.0, acc1 = 0.0;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
     const Rk45State *st = a.st;
     const double *yfin = st->last_accepted ? a.ynew : a.y;
     TrunkPre<P> pre;
-    trunk_begin<P>(net, pre);
+    trunk_begin<P>(net, pre, a.cvec, a.tvec, row0, a.nrows, a.kcand);
     if (tid < P) {
         const int r = row0 + tid < a.nrows ? row0 + tid : a.nrows - 1;
         float *xr = lds + tid * L::LD0;

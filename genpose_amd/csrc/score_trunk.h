@@ -23,32 +23,98 @@ struct TrunkCfg {
     static constexpr int NT = 64 * NW;   // threads per workgroup
 };
 
-// LDS layout for a P-row tile (floats):  X0 [P][16+8] | H1 [P][256+8] | H2 [P][256+8] | red [4*NW][P][12]
+// LDS layout for a P-row tile (floats):
+//   X0 [P][16+8] | H1 [P][256+8] | H2 [P][256+8] | red [4*NW][P][12] | wout [9][256] | cvt [2][768+16]
+// wout / cvt = the head epilogue's operands, staged once per launch while the prologue waits on its own loads:
+// cvt[c] = cvec[first cloud of the tile + c] + tvec.  (Read back with broadcast ds_read_b128; fetching them from global
+// memory in the epilogue costs 1.1-1.7 k cycles per head, and requesting them under the MFMA loop slows the weight
+// stream by more than that - the vector memory path is the loop's bottleneck.)
 template <int P>
 struct TrunkLds {
-    static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD;
+    static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD, LDC = HEADS + 16;
     static constexpr int OFF_H1 = P * LD0, OFF_H2 = OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH,
-                         TOTAL = OFF_RED + 4 * TrunkCfg<P>::NW * P * 12;
+                         OFF_WOUT = OFF_RED + 4 * TrunkCfg<P>::NW * P * 12, OFF_CVT = OFF_WOUT + POSE * HID,
+                         TOTAL = OFF_CVT + 2 * LDC;
 };
 
-template <int NV>
+template <int NV, int NI>
 struct TrunkPreT {
     WStages<NV> stA;  // first-layer weights (stages 0,1)
     f32x4 b0[NV];     // first-layer bias fragments
+    float bout[NI];   // output bias of the (row, component) entries this thread combines at the end
+    // epilogue operands in flight to LDS (trunk_begin requests, trunk_ftheta parks them)
+    static constexpr int NWO = (POSE * HID / 4 + 64 * (16 / NV) - 1) / (64 * (16 / NV));   // float4 per thread: w_out
+    static constexpr int NCV = (2 * HEADS / 4 + 64 * (16 / NV) - 1) / (64 * (16 / NV));    // float4 per thread: cvt
+    f32x4 swo[NWO], scv[NCV], stv[NCV];
+    GpStamps ts;     // tuning builds only
+    int cloud0;      // first cloud of the tile
+    bool staged;     // tile spans <= 2 clouds (else the epilogue reads cvec/tvec from global memory)
 };
 template <int P>
-using TrunkPre = TrunkPreT<TrunkCfg<P>::NV>;
+using TrunkPre = TrunkPreT<TrunkCfg<P>::NV, (P * 9 + TrunkCfg<P>::NT - 1) / TrunkCfg<P>::NT>;
 
 // Entry sequence shared by every kernel that evaluates the trunk: request the first layer's weights and bias
 // (call BEFORE any prologue work so the latency overlaps it).
 template <int P>
-__device__ __forceinline__ void trunk_begin(const gp_scorenet &net, TrunkPre<P> &pre) {
-    constexpr int NW = TrunkCfg<P>::NW, NV = TrunkCfg<P>::NV;
+__device__ __forceinline__ void trunk_begin(const gp_scorenet &net, TrunkPre<P> &pre, const float *__restrict__ cvec,
+                                            const float *__restrict__ tvec, int row0, int nrows, int kcand) {
+    constexpr int NW = TrunkCfg<P>::NW, NV = TrunkCfg<P>::NV, NT = TrunkCfg<P>::NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ncl[4] = {wave, wave + NW, wave + 2 * NW, wave + 3 * NW};  // first NV entries are this wave's chunks
     mfma_preload<NV>(pre.stA, net.w_pose0, 1, HID / 16, ncl);
 #pragma unroll
     for (int i = 0; i < NV; ++i) pre.b0[i] = *reinterpret_cast<const f32x4 *>(net.b_pose0 + ncl[i] * 16 + 4 * (lane >> 4));
+    constexpr int NI = (P * POSE + NT - 1) / NT;
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        pre.bout[q] = net.b_out[(threadIdx.x + q * NT) % POSE];
+        gp_pin(pre.bout[q]);
+    }
+    // epilogue operands -> registers now, LDS later (trunk_ftheta)
+    const int rlast = (row0 + P - 1 < nrows ? row0 + P - 1 : nrows - 1);
+    pre.cloud0 = row0 / kcand;
+    pre.staged = rlast / kcand - pre.cloud0 <= 1;
+#pragma unroll
+    for (int q = 0; q < TrunkPre<P>::NWO; ++q) {
+        int f = threadIdx.x + q * NT;
+        f = f < POSE * HID / 4 ? f : POSE * HID / 4 - 1;
+        pre.swo[q] = reinterpret_cast<const f32x4 *>(net.w_out)[f];
+    }
+    if (pre.staged) {
+        const int nclouds = (nrows + kcand - 1) / kcand;
+#pragma unroll
+        for (int q = 0; q < TrunkPre<P>::NCV; ++q) {
+            int f = threadIdx.x + q * NT;
+            f = f < 2 * HEADS / 4 ? f : 2 * HEADS / 4 - 1;
+            const int c = f / (HEADS / 4), o = f - c * (HEADS / 4);
+            int cl = pre.cloud0 + c;
+            cl = cl < nclouds ? cl : nclouds - 1;
+            pre.scv[q] = reinterpret_cast<const f32x4 *>(cvec + (size_t)cl * HEADS)[o];
+            pre.stv[q] = reinterpret_cast<const f32x4 *>(tvec)[o];
+        }
+    }
+}
+
+// parks the staged epilogue operands in LDS (visible after the next __syncthreads())
+template <int P>
+__device__ __forceinline__ void trunk_park_epi(float *lds, TrunkPre<P> &pre) {
+    using L = TrunkLds<P>;
+    constexpr int NT = TrunkCfg<P>::NT;
+#pragma unroll
+    for (int q = 0; q < TrunkPre<P>::NWO; ++q) {
+        const int f = threadIdx.x + q * NT;
+        if (f < POSE * HID / 4) reinterpret_cast<f32x4 *>(lds + L::OFF_WOUT)[f] = pre.swo[q];
+    }
+    if (pre.staged) {
+#pragma unroll
+        for (int q = 0; q < TrunkPre<P>::NCV; ++q) {
+            const int f = threadIdx.x + q * NT;
+            if (f < 2 * HEADS / 4) {
+                const int c = f / (HEADS / 4), o = f - c * (HEADS / 4);
+                *reinterpret_cast<f32x4 *>(lds + L::OFF_CVT + c * L::LDC + 4 * o) = pre.scv[q] + pre.stv[q];
+            }
+        }
+    }
 }
 
 // dense 256-wide layer of the trunk on pre-requested weights and bias: out = relu(X W^T + b) -> LDS.
@@ -75,26 +141,32 @@ __device__ __forceinline__ void trunk_dense(WStages<16 / NW> &st, const f32x4 (&
     }
 }
 
-// epilogue operands of one head for this wave's four 16-channel chunks
+// epilogue operands of one head for this wave's 16-channel chunks: cv = cvec[cloud of the row] + tvec (pre-added)
 template <int PT, int NV>
 struct HeadOps {
-    f32x4 tv[NV], w0[NV], w1[NV], w2[NV], cv[NV][PT];
+    f32x4 w0[NV], w1[NV], w2[NV], cv[NV][PT];
 };
 
-template <int PT, int NV>
-__device__ __forceinline__ void head_ops_load(HeadOps<PT, NV> &o, const gp_scorenet &net, const float *__restrict__ cvec,
-                                              const float *__restrict__ tvec, int h, const int (&nc)[4], const int (&cloud)[PT]) {
+template <int P, int PT, int NV>
+__device__ __forceinline__ void head_ops_load(HeadOps<PT, NV> &o, const float *lds, bool staged, const float *__restrict__ cvec,
+                                              const float *__restrict__ tvec, int h, const int (&nc)[4], const int (&cloud)[PT], int cloud0) {
+    using L = TrunkLds<P>;
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int ch = nc[i] * 16 + 4 * (lane >> 4);  // 0..767
         const int chh = ch - 256 * h;
-        o.tv[i] = *reinterpret_cast<const f32x4 *>(tvec + ch);
-        o.w0[i] = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 0) * HID + chh);
-        o.w1[i] = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 1) * HID + chh);
-        o.w2[i] = *reinterpret_cast<const f32x4 *>(net.w_out + (3 * h + 2) * HID + chh);
+        o.w0[i] = *reinterpret_cast<const f32x4 *>(lds + L::OFF_WOUT + (3 * h + 0) * HID + chh);
+        o.w1[i] = *reinterpret_cast<const f32x4 *>(lds + L::OFF_WOUT + (3 * h + 1) * HID + chh);
+        o.w2[i] = *reinterpret_cast<const f32x4 *>(lds + L::OFF_WOUT + (3 * h + 2) * HID + chh);
+        if (staged) {
 #pragma unroll
-        for (int p = 0; p < PT; ++p) o.cv[i][p] = *reinterpret_cast<const f32x4 *>(cvec + (size_t)cloud[p] * HEADS + ch);
+            for (int p = 0; p < PT; ++p) o.cv[i][p] = *reinterpret_cast<const f32x4 *>(lds + L::OFF_CVT + (cloud[p] - cloud0) * L::LDC + ch);
+        } else {
+            const f32x4 tv = *reinterpret_cast<const f32x4 *>(tvec + ch);
+#pragma unroll
+            for (int p = 0; p < PT; ++p) o.cv[i][p] = *reinterpret_cast<const f32x4 *>(cvec + (size_t)cloud[p] * HEADS + ch) + tv;
+        }
     }
 }
 
@@ -121,6 +193,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         if (r >= nrows) r = nrows - 1;
         cloud[p] = r / kcand;
     }
+    trunk_park_epi<P>(lds, pre);  // visible after the barrier that follows layer 1
     GP_T(2);
     // ---- layer 1 (9 -> 256); layer 2's first weight stages and bias are requested before it runs
     WStages<NV> stB;
@@ -143,14 +216,12 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
     for (int h = 0; h < 3; ++h) {
         f32x4 acc[4][PT];
         GP_T(6 + 3 * h);
-        // next head's first weight stages are requested before this head runs (hides the cold start).  The epilogue
-        // operands are NOT hoisted above the MFMA loop: measured slower (their ~20 KB/wave of broadcast loads queue
-        // in front of the loop's counted weight prefetches).
+        // next head's first weight stages are requested before this head runs (hides the cold start)
         if (h < 2) mfma_preload<NV>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
         mfma_run<NV, PT>(stH[h & 1], H2, L::LDH, 0, net.w_headx, HID / 16, HEADS / 16, nch[h], acc);
         GP_T(7 + 3 * h);
         HeadOps<PT, NV> o;
-        head_ops_load<PT, NV>(o, net, cvec, tvec, h, nch[h], cloud);
+        head_ops_load<P, PT, NV>(o, lds, pre.staged, cvec, tvec, h, nch[h], cloud, pre.cloud0);
         float part[PT][3];  // [p-chunk][component], this wave's n-chunks of head h
 #pragma unroll
         for (int p = 0; p < PT; ++p) part[p][0] = part[p][1] = part[p][2] = 0.f;
@@ -158,7 +229,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         for (int i = 0; i < NV; ++i) {
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
-                f32x4 v = acc[i][p] + o.cv[i][p] + o.tv[i];
+                f32x4 v = acc[i][p] + o.cv[i][p];
                 v.x = fmaxf(v.x, 0.f);
                 v.y = fmaxf(v.y, 0.f);
                 v.z = fmaxf(v.z, 0.f);
@@ -176,12 +247,17 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         GP_T(8 + 3 * h);
     }
     __syncthreads();
-    for (int e = tid; e < P * POSE; e += NT) {
-        const int r = e / POSE, j = e - r * POSE;
-        float v = 0.f;
+    constexpr int NI = (P * POSE + NT - 1) / NT;
 #pragma unroll
-        for (int q = 0; q < 4 * NW; ++q) v += red[(q * P + r) * 12 + j];
-        H1[r * L::LDH + j] = v + net.b_out[j];  // parked in H1 (free now)
+    for (int it = 0; it < NI; ++it) {
+        const int e = tid + it * NT;
+        if (e < P * POSE) {
+            const int r = e / POSE, j = e - r * POSE;
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4 * NW; ++q) v += red[(q * P + r) * 12 + j];
+            H1[r * L::LDH + j] = v + pre.bout[it];  // parked in H1 (free now)
+        }
     }
     __syncthreads();
 }

@@ -77,11 +77,12 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void score_eval_kernel(int nrows, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int row0 = blockIdx.x * P, tid = threadIdx.x;
     TrunkPre<P> pre;
-    trunk_begin<P>(net, pre);
+    trunk_begin<P>(net, pre, cvec, tvec, row0, nrows, kcand);
+    float sigma = *sigma_dev;  // requested now, used after the trunk
+    gp_pin(sigma);
     load_x_tile<P>(lds, x, row0, nrows);
     __syncthreads();
     trunk_ftheta<P>(lds, net, cvec, tvec, row0, nrows, kcand, pre);
-    const float sigma = *sigma_dev;
     const float *F = lds + L::OFF_H1;
     if (mode == 0) {
         for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
@@ -124,9 +125,14 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_gn;
     const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
-    if (i < a.nsteps) GP_T(0);
     TrunkPre<P> pre;
-    if (i < a.nsteps) trunk_begin<P>(net, pre);
+    GP_T(0);
+    float sigma = 1.f;
+    if (i < a.nsteps) {
+        trunk_begin<P>(net, pre, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand);
+        sigma = a.sched[(size_t)i * 4 + 0];  // requested now, used after the trunk
+        gp_pin(sigma);
+    }
     if (i > 0) {
         // (1) row threads request their operands first; (2) meanwhile the last wave reduces the per-block partial sums
         // of step i-1 into the batch-mean gradient norm (fixed order: deterministic); (3) one barrier, then the update.
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
             if (tid == LASTW) s_gn = s / (float)a.nrows;
         }
         __syncthreads();
-        if (i < a.nsteps) GP_T(20);
+        GP_T(19);
         if (tid < P) {
             const float q = 0.48f / s_gn;  // snr * sqrt(pose_dim) = 0.16 * 3
             const float lstep = 2.0f * (q * q);
@@ -213,7 +219,6 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     GP_T(1);
     trunk_ftheta<P>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre);
     GP_T(16);
-    const float sigma = a.sched[(size_t)i * 4 + 0];
     float *F = lds + L::OFF_H1;
     for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
         const int r = e / POSE, j = e - r * POSE;
@@ -232,11 +237,11 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
                 s += sqrtf(q);
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        s = wave_sum_f32(s);
         if (tid == 0) a.partials[(size_t)i * a.nblocks + blockIdx.x] = s;
     }
     GP_T(17);
+    GP_T_FLUSH();
 }
 
 }  // namespace

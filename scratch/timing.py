@@ -16,7 +16,7 @@ l = _lib.lib(); l.gp_debug_timestamps.argtypes = [ctypes.c_void_p]
 buf = (ctypes.c_ulonglong * 128)()
 assert l.gp_debug_timestamps(buf) == 0
 ts = np.array(buf, dtype=np.uint64).reshape(4, 32).astype(np.int64)
-names = {0: "start", 20: "loads+gn", 1: "prologue done", 2: "trunk in", 3: "L1 done(+bar)", 4: "L2 mfma+epi", 5: "L2 barrier", 6: "h0 start", 7: "h0 mfma", 8: "h0 epi",
+names = {0: "start", 19: "loads+gn", 1: "prologue done", 2: "trunk in", 3: "L1 done(+bar)", 4: "L2 mfma+epi", 5: "L2 barrier", 6: "h0 start", 7: "h0 mfma", 8: "h0 epi",
          9: "h1 start", 10: "h1 mfma", 11: "h1 epi", 12: "h2 start", 13: "h2 mfma", 14: "h2 epi", 16: "trunk out", 17: "end"}
 for w in range(4):
     t0 = ts[w, 0]
