@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--sampler", choices=["pc", "ode"], default="pc")
     ap.add_argument("--pipeline", choices=["score", "full"], default="score")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another on one stream")
+    ap.add_argument("--batches-per-launch", type=int, default=2,
+                    help="pipelined PC workload: consecutive batches that share one encoder pass and one sampler launch chain "
+                         "(the sampler's batch-global coupling stays per batch); 1 = one batch per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clouds", type=int, default=4)
     return ap.parse_args()
@@ -111,7 +114,8 @@ def main():
     pipe = None
     if pipelined:
         from genpose_amd.pipeline import PipelinedPCPredictor
-        pipe = PipelinedPCPredictor(score_agent, B, K, n)
+        pipe = PipelinedPCPredictor(score_agent, B, K, n, batches_per_launch=args.batches_per_launch)
+    G = args.batches_per_launch if pipelined else 1
 
     def run_steps(count):
         if not pipelined:
@@ -125,6 +129,8 @@ def main():
                 dist.all_gather(gathered, o)
 
     step()  # builds samplers / captures graphs outside the timed region
+    if pipelined:
+        run_steps(2 * G + 1)  # captures the G-batch graph and the 1-batch graph of a ragged tail
     run_steps(args.warmup)
     barrier()
     if pipe is not None:
@@ -147,7 +153,7 @@ def main():
     roofline = None
     nfev = n
     if args.sampler == "pc":
-        smp = score_agent.net._samplers[("pc", B, K, n, False)]
+        smp = pipe._sampler(0, G) if pipe is not None else score_agent.net._samplers[("pc", B, K, n, False)]
         reps = 5
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -162,18 +168,17 @@ def main():
         # profiler serialises the two streams: profiles/r1_bench_kernel_stats.csv).  In the pipelined timed region the
         # launches share the chip with the encoder of the next step, so their in-situ duration is longer; it is
         # reported next to it (events around every graph replay inside the timed region).
-        flops_per_launch = B * K * FLOP_SCORE_ROW
+        flops_per_launch = G * B * K * FLOP_SCORE_ROW  # one launch serves G batches
         ach = flops_per_launch / per_launch_s / 1e12
-        from genpose_amd import _lib as gp_lib
-        roofline = {"bound": "mfma", "kernel": f"pc_step_kernel<{gp_lib.lib().gp_score_tile_rows(B * K)}>", "achieved": round(ach, 2),
+        roofline = {"bound": "mfma", "kernel": f"pc_step_kernel<{smp.tile}>", "rows_per_launch": G * B * K, "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                     "avg_launch_us": round(per_launch_s * 1e6, 2), "flops_per_launch": flops_per_launch}
         # HBM-side bytes per launch come from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in separate
         # rocprofv3 runs, gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); only valid for the profiled shape
         tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if B * K == 3200 and os.path.exists(tpath):
+        if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))[roofline["kernel"]]
+                tj = json.load(open(tpath))[f"{roofline['kernel']}@{G * B * K}"]
                 roofline["traffic"] = tj["corrected_bytes_per_launch"]
                 roofline["traffic_note"] = (f"PMC, profiles/r1_pmc_traffic.json: raw {tj['raw_bytes_per_launch']} B, algorithmic "
                                             f"{tj['algorithmic_bytes_per_launch']} B; Infinity-Cache hits are counted (the 1 MB weight set "
@@ -203,7 +208,7 @@ def main():
             "config": {"workload": f"configs[1]: {B} clouds/GPU x 1024 pts, {K} candidates, "
                                    + (f"PC sampler {n} steps (NFE={n})" if args.sampler == "pc" else f"ODE sampler RK45 T0={T0} (NFE={nfev})")
                                    + (", ScoreNet only" if energy_agent is None else ", + EnergyNet ranking + top-60% aggregation"),
-                       "clouds_per_gpu": B, "candidates": K, "sde_steps": n, "sampler": args.sampler, "pipeline": args.pipeline, "stream_pipelining": bool(pipelined),
+                       "clouds_per_gpu": B, "candidates": K, "sde_steps": n, "sampler": args.sampler, "pipeline": args.pipeline, "stream_pipelining": bool(pipelined), "batches_per_launch": G,
                        "weights": "seeded random (reference state-dict schema)", "parallelism": f"clouds sharded x{world}"},
             "whole_path_tflops": round(value * flop_per_pose / 1e12, 2),
             "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3),

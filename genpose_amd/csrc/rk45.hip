@@ -35,6 +35,7 @@ constexpr double SIG_MIN = 0.01, SIG_RATIO = 50.0 / 0.01;
 struct Rk45State {
     double t, h_abs, t_bound, direction, rtol, atol;
     double h;              // signed step of the attempt in flight
+    double t_new;          // its end point (exactly t_bound on the last step - rk.py keeps t_new, not t + h)
     double d0, d1, h0;     // initial-step scratch
     double err_norm;       // of the last attempt
     int status;            // 0 running, 1 finished, -1 step size too small
@@ -207,6 +208,7 @@ __device__ void begin_attempt(Rk45State *st) {
     double h = h_abs * dir, t_new = t + h;
     if (dir * (t_new - st->t_bound) > 0) t_new = st->t_bound;
     h = t_new - t;
+    st->t_new = t_new;
     st->h = h;
     st->h_abs = fabs(h);
     for (int s = 1; s <= 6; ++s) set_stage(st, s, t + DP_C[s] * h);
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
                 h_abs *= factor;
                 st->t_old = st->t;
                 st->h_acc = st->h;
-                st->t = st->t + st->h;  // t_new (already clamped to t_bound in begin_attempt)
+                st->t = st->t_new;  // rk.py:169 (clamped to t_bound in begin_attempt; t + h can miss it by an ulp)
                 if (st->n_eval > 0) {   // ivp.py: every not-yet-emitted t_eval point the step has passed (inclusive of t_new)
                     int m = st->next_eval;
                     st->emit_begin = m;

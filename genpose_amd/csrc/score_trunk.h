@@ -9,16 +9,20 @@ namespace gp_trunk {
 constexpr int HID = 256, HEADS = 768, POSE = 9;
 
 // ---------------------------------------------------------------------------------------------- trunk
-// Waves per workgroup.  Measured on MI355X at R = 3200 (16-row tiles, one workgroup per CU): 8 waves (two per SIMD) = 26.4 us
-// per sampler step vs 26.0 us with 4 - the phases are barrier-locked, so a second wave per SIMD has nothing different to
-// overlap with.  4 it is; build with -DGP_TRUNK_8W to re-measure.
+// Waves per workgroup.  Measured on MI355X (sampler launch, K = 50):
+//   16-row tile, R = 3200: 8 waves (two per SIMD) 24.3 us vs 24.3 us with 4 - the tile is bound by the weight stream and its
+//                          phases are barrier-locked, a second wave per SIMD has nothing different to overlap with;
+//   32-row tile, R = 6400: 8 waves 39.2 us vs 40.9 us with 4 - MFMA-bound, the second wave fills epilogue / barrier bubbles.
+// -DGP_TRUNK_NW16= / -DGP_TRUNK_NW32= re-measure.
+#ifndef GP_TRUNK_NW16
+#define GP_TRUNK_NW16 4
+#endif
+#ifndef GP_TRUNK_NW32
+#define GP_TRUNK_NW32 8
+#endif
 template <int P>
 struct TrunkCfg {
-#ifdef GP_TRUNK_8W
-    static constexpr int NW = (P <= 16) ? 8 : 4;
-#else
-    static constexpr int NW = 4;
-#endif
+    static constexpr int NW = (P <= 16) ? GP_TRUNK_NW16 : GP_TRUNK_NW32;
     static constexpr int NV = 16 / NW;   // 16-channel chunks of a 256-wide layer per wave
     static constexpr int NT = 64 * NW;   // threads per workgroup
 };
@@ -279,8 +283,11 @@ constexpr size_t trunk_lds_bytes() {
     return (size_t)TrunkLds<P>::TOTAL * sizeof(float);
 }
 
-// Rows per workgroup tile: 32 when that still gives >= 1.5 workgroups per CU, else 16 (fills more of the 256 CUs:
-// the kernels are MFMA-bound per CU, so small batches want more, smaller tiles).  GP_SCORE_P overrides (tuning).
+// Rows per workgroup tile.  With 16 rows every weight fragment feeds one MFMA and the kernel is bound by the CU's
+// L2->VGPR streaming rate (~26 us per round of <= 256 tiles, two tiles co-resident per CU stream twice the bytes); with
+// 32 rows it is MFMA-bound (~42 us per round of <= 256 tiles, one per CU).  Measured on MI355X, K = 50:
+//   R = 3200: 26 / 42 us    6400: 53 / 42    9600: 74 / 82    12800: 98 / 83   (16 / 32 rows)
+// -> pick the smaller of 13*rounds(16) and 21*rounds(32).  GP_SCORE_P overrides (tuning).
 static inline int score_tile_rows(int nrows) {
     static int forced = -1;
     if (forced < 0) {
@@ -288,7 +295,8 @@ static inline int score_tile_rows(int nrows) {
         forced = e ? atoi(e) : 0;
     }
     if (forced == 16 || forced == 32) return forced;
-    return ((nrows + 31) / 32 >= 384) ? 32 : 16;
+    const int r16 = ((nrows + 15) / 16 + 255) / 256, r32 = ((nrows + 31) / 32 + 255) / 256;
+    return 21 * r32 < 13 * r16 ? 32 : 16;
 }
 
 // Gram-Schmidt of pytorch3d.rotation_6d_to_matrix + GenPose's column write-back (utils/misc.py:259-265):

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void score_eval_kernel(int nrows, 
 // ---------------------------------------------------------------------------------------------- PC sampler
 struct PcArgs {
     int nrows, kcand, step, nsteps, nblocks;
+    int bpg, rows_per_group;         // blocks / rows of one batch (group): the batch-mean gradient norm is per group
     const float *cvec, *tvec_all;    // tvec_all [nsteps][768]
     const float *sched;              // [nsteps][4]: sigma(t_i), g(t_i), step_size, sqrt(step_size)  (f32, host schedule)
     const float *z_lang, *z_pred;    // [nsteps][R][9]
@@ -157,10 +158,10 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         constexpr int LASTW = TrunkCfg<P>::NT - 64;
         if (tid >= LASTW) {
             float s = 0.f;
-            const float *pp = a.partials + (size_t)(i - 1) * a.nblocks;
-            for (int q = tid - LASTW; q < a.nblocks; q += 64) s += pp[q];
+            const float *pp = a.partials + (size_t)(i - 1) * a.nblocks + (size_t)(blockIdx.x / a.bpg) * a.bpg;
+            for (int q = tid - LASTW; q < a.bpg; q += 64) s += pp[q];
             s = wave_sum_f32(s);
-            if (tid == LASTW) s_gn = s / (float)a.nrows;
+            if (tid == LASTW) s_gn = s / (float)a.rows_per_group;
         }
         __syncthreads();
         GP_T(19);
@@ -296,17 +297,28 @@ int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec,
     return gp_launch_status();
 }
 
-int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec, const float *tvec_all,
-               const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
-               float *score, float *partials, float *traj, gp_stream_t s) {
-    if (nclouds < 0 || k <= 0 || step < 0 || step > nsteps || !net || !cvec || !tvec_all || !sched || !z_langevin || !z_predictor ||
-        !centre || !x || !mean_x || !score || !partials)
+int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k) {
+    if (ngroups <= 0 || nclouds_per_group < 0 || k <= 0) return GP_EINVAL;
+    const int rg = nclouds_per_group * k;
+    int P = score_tile_rows(ngroups * rg);
+    if (ngroups > 1 && rg % P != 0) P = 16;  // tiles must not straddle groups
+    if (ngroups > 1 && rg % P != 0) return GP_EINVAL;
+    return P;
+}
+
+int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+                       const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
+                       float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s) {
+    if (ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || step < 0 || step > nsteps || !net || !cvec || !tvec_all || !sched || !z_langevin ||
+        !z_predictor || !centre || !x || !mean_x || !score || !partials)
         return GP_EINVAL;
-    const int R = nclouds * k;
+    const int rg = nclouds_per_group * k, R = ngroups * rg;
     if (R == 0) return GP_OK;
+    const int P = gp_pc_tile_rows(ngroups, nclouds_per_group, k);
+    if (P < 0) return P;
     PcArgs a;
-    const int P = score_tile_rows(R);
-    a.nrows = R, a.kcand = k, a.step = step, a.nsteps = nsteps, a.nblocks = (R + P - 1) / P;
+    a.nrows = R, a.kcand = k, a.step = step, a.nsteps = nsteps;
+    a.bpg = (rg + P - 1) / P, a.rows_per_group = rg, a.nblocks = a.bpg * ngroups;
     a.cvec = cvec, a.tvec_all = tvec_all, a.sched = sched, a.z_lang = z_langevin, a.z_pred = z_predictor, a.centre = centre;
     a.x = x, a.mean_x = mean_x, a.score = score, a.partials = partials, a.traj = traj;
     static bool attr_done = false;
@@ -323,6 +335,13 @@ int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net,
     else
         hipLaunchKernelGGL(pc_step_kernel<32>, dim3(a.nblocks), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), (hipStream_t)s, a, *net);
     return gp_launch_status();
+}
+
+int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec, const float *tvec_all,
+               const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
+               float *score, float *partials, float *traj, gp_stream_t s) {
+    return gp_pc_step_grouped(1, nclouds, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
+                              partials, traj, s);
 }
 
 }  // extern "C"

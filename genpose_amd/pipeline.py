@@ -17,10 +17,16 @@ class PipelinedPCPredictor:
     score_agent : genpose_amd.posenet_agent.PoseNet (weights loaded, sampler_mode ['pc'])
     """
 
-    def __init__(self, score_agent, B, K, num_steps, depth=2, sampler_streams=1):
+    def __init__(self, score_agent, B, K, num_steps, depth=2, sampler_streams=1, batches_per_launch=1):
+        """batches_per_launch = G > 1: G consecutive batches share every encoder and sampler launch (the batch-global
+        coupling of the sampler stays per batch - gp_pc_step_grouped); at B*K = 3200 rows this lets the sampler run on
+        32-row tiles (MFMA-bound) instead of 16-row tiles (weight-stream-bound): 21 vs 26 us per batch and step."""
         _lib.check_device()
         self.net = score_agent.net
         self.net._need_weights()
+        self.G = batches_per_launch
+        self.B1 = B                      # clouds per batch (the unit of the batch-global coupling)
+        B = B * self.G                   # clouds per launch
         self.B, self.K, self.n, self.depth = B, K, num_steps, depth
         self.dev = self.net.device
         # the sampler is a latency-critical serial chain of short launches: its stream gets the HIGH hardware queue
@@ -29,7 +35,7 @@ class PipelinedPCPredictor:
         # (sampler_streams > 1 puts several sampler chains in flight; measured SLOWER at the bench configuration:
         #  13.1 k vs 14.2 k poses/s - the chains contend for the same MFMA pipes and each step boundary gets longer)
         self.s_smp = [torch.cuda.Stream(self.dev, priority=-1) for _ in range(sampler_streams)]
-        self.smp = [PCSampler(self.net.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False)
+        self.smp = [{self.G: PCSampler(self.net.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False, groups=self.G)}
                     for _ in range(sampler_streams)]
         self.timing = False
         self.smp_events = []
@@ -44,6 +50,11 @@ class PipelinedPCPredictor:
         for e in self.ev_free:
             e.record(self.s_smp[0])
 
+    def _sampler(self, j, g):
+        if g not in self.smp[j]:  # ragged tail of a run: fewer batches in the last launch
+            self.smp[j][g] = PCSampler(self.net.pose_score_net, self.B1 * g, self.K, self.n, self.dev, use_graph=True, record_traj=False, groups=g)
+        return self.smp[j][g]
+
     def run(self, batches, prior_noise=None, noise=None, out=None):
         """batches: sequence of device tensors [B,1024,3].  prior_noise / noise: optional per-batch explicit draws (tests).
         Returns a list of pred_pose [B,K,9] float32 tensors (one per batch; written into `out[i]` when given)."""
@@ -52,37 +63,50 @@ class PipelinedPCPredictor:
         self.s_enc.wait_stream(cur)
         for st in self.s_smp:
             st.wait_stream(cur)
-        for i, pts in enumerate(batches):
-            slot = i % self.depth
+        B1, K, G = self.B1, self.K, self.G
+        for c, i0 in enumerate(range(0, len(batches), G)):
+            group = batches[i0:i0 + G]
+            g = len(group)
+            nb, nr = g * B1, g * B1 * K
+            slot = c % self.depth
             # ---- encoder stage (stream E): features -> per-cloud embedding, prior -> device
             with torch.cuda.stream(self.s_enc):
                 self.s_enc.wait_event(self.ev_free[slot])  # the sampler has consumed this slot's previous contents
+                pts = group[0] if g == 1 else torch.cat(list(group), dim=0)
                 feat = self.net.pts_encoder(pts)
                 cv = self.net.pose_score_net.cloud_embed(feat)
-                self.cvec[slot].copy_(cv)
-                self.centre[slot].copy_(pts.mean(dim=1))
+                self.cvec[slot][:nb].copy_(cv)
+                self.centre[slot][:nb].copy_(pts.mean(dim=1))
+                x0 = self.x0[slot][:nr]
                 if prior_noise is None:
-                    self.ev_h2d[slot].synchronize()  # host may run `depth` batches ahead, not further (pinned buffer reuse)
-                    torch.randn(self.prior_host[slot].shape, out=self.prior_host[slot])  # CPU generator, as sde.py:28
-                    self.x0[slot].copy_(self.prior_host[slot], non_blocking=True)
+                    self.ev_h2d[slot].synchronize()  # host may run `depth` launches ahead, not further (pinned buffer reuse)
+                    host = self.prior_host[slot][:nr]
+                    torch.randn(host.shape, out=host)  # CPU generator, as sde.py:28
+                    x0.copy_(host, non_blocking=True)
                     self.ev_h2d[slot].record(self.s_enc)
                 else:
-                    self.x0[slot].copy_(prior_noise[i])
-                self.x0[slot].mul_(SIGMA_MAX)  # prior std at T = 1 (cond_pc_sampler always starts from T = 1)
+                    x0.copy_(torch.cat([prior_noise[i0 + q].reshape(B1 * K, 9) for q in range(g)], dim=0))
+                x0.mul_(SIGMA_MAX)  # prior std at T = 1 (cond_pc_sampler always starts from T = 1)
                 self.ev_enc[slot].record(self.s_enc)
             # ---- sampler stage (stream S): the whole T-step loop as one graph replay
-            j = i % len(self.s_smp)
+            j = c % len(self.s_smp)
             with torch.cuda.stream(self.s_smp[j]):
                 self.s_smp[j].wait_event(self.ev_enc[slot])
-                z1, z2 = noise[i] if noise is not None else (None, None)
+                if noise is not None:
+                    z1 = torch.cat([noise[i0 + q][0] for q in range(g)], dim=1)
+                    z2 = torch.cat([noise[i0 + q][1] for q in range(g)], dim=1)
+                else:
+                    z1 = z2 = None
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.timing else None
-                _, mean_x = self.smp[j].run(self.cvec[slot], self.centre[slot], self.x0[slot], z1, z2, slot_free_event=self.ev_free[slot],
-                                            graph_events=ev)
-                res = out[i] if out is not None else torch.empty(self.B, self.K, 9, device=self.dev)
-                res.copy_(mean_x.reshape(self.B, self.K, 9))
-                results.append(res)
+                _, mean_x = self._sampler(j, g).run(self.cvec[slot][:nb], self.centre[slot][:nb], x0, z1, z2, slot_free_event=self.ev_free[slot],
+                                                    graph_events=ev)
+                mean_x = mean_x.reshape(g, B1, K, 9)
+                for q in range(g):
+                    res = out[i0 + q] if out is not None else torch.empty(B1, K, 9, device=self.dev)
+                    res.copy_(mean_x[q])
+                    results.append(res)
                 if ev is not None:
-                    self.smp_events.append(ev)
+                    self.smp_events.append(ev + (g,))
         for st in self.s_smp:
             cur.wait_stream(st)
         cur.wait_stream(self.s_enc)
@@ -93,5 +117,5 @@ class PipelinedPCPredictor:
         the sampler streams; call after a synchronize)."""
         if not self.smp_events:
             return None
-        tot = sum(a.elapsed_time(b) for a, b in self.smp_events) * 1e-3
+        tot = sum(a.elapsed_time(b) for a, b, _ in self.smp_events) * 1e-3
         return tot / (len(self.smp_events) * (self.n + 1))

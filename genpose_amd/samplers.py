@@ -25,13 +25,19 @@ def pc_schedule(num_steps, eps=EPS):
 class PCSampler:
     """Predictor-corrector sampler state for a fixed (B, K, num_steps): buffers + optional hipGraph of the whole loop."""
 
-    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False):
-        self.net, self.B, self.K, self.n = net, B, K, num_steps
+    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1):
+        """B clouds in `groups` independent batches of B/groups clouds laid out back to back: one launch chain serves all of
+        them, the batch-mean gradient norm (samplers.py:130-132) stays per batch (gp_pc_step_grouped)."""
+        if B % groups:
+            raise ValueError(f"{B} clouds do not split into {groups} equal batches")
+        self.net, self.B, self.K, self.n, self.groups = net, B, K, num_steps, groups
         self.dev = torch.device(device)
         R = B * K
         self.R = R
-        self.tile = _lib.lib().gp_score_tile_rows(R)
-        self.nblocks = (R + self.tile - 1) // self.tile
+        self.tile = _lib.lib().gp_pc_tile_rows(groups, B // groups, K)
+        if self.tile < 0:
+            raise ValueError(f"{B // groups} clouds x {K} candidates per batch is not a multiple of the 16-row tile; run the batches separately")
+        self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)
         self.tvec_all = net.time_embed(ts.to(self.dev))
@@ -48,7 +54,7 @@ class PCSampler:
         st = stream_ptr()
         w = self.net.w.ref()
         for i in range(self.n + 1):
-            _lib.call("gp_pc_step", self.B, self.K, i, self.n, w, ptr(self.cvec), ptr(self.tvec_all), ptr(self.sched), ptr(self.z1),
+            _lib.call("gp_pc_step_grouped", self.groups, self.B // self.groups, self.K, i, self.n, w, ptr(self.cvec), ptr(self.tvec_all), ptr(self.sched), ptr(self.z1),
                       ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
                       ptr(self.traj), st)
 

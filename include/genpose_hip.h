@@ -162,6 +162,17 @@ int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net,
                const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
                float *score, float *partials, float *traj, gp_stream_t s);
 
+/* The same launch over `ngroups` independent batches of `nclouds_per_group` clouds laid out back to back (rows, clouds,
+ * noise: group-major).  Everything is row-local except the batch-mean gradient norm, which stays PER GROUP, so every
+ * group's result is what gp_pc_step returns for it alone (up to the summation order of the norm partials); serving
+ * two batches per launch lets the kernel use 32-row tiles (MFMA-bound) where one batch only fills 16-row tiles
+ * (weight-stream-bound).  Rows of one group must be a multiple of the tile: gp_pc_tile_rows() returns the tile
+ * (16 or 32) or GP_EINVAL.  partials: [nsteps][ngroups * ceil(rows_per_group / tile)]. */
+int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k);
+int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+                       const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor,
+                       const float *centre, float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s);
+
 /* Probability-flow ODE sampler = cond_ode_sampler (samplers.py:163-227) over scipy's RK45 (rk.py / common.py):
  * Dormand-Prince 5(4), f64 state and controller resident in device memory, f32 score network, batch-global RMS
  * error norm, SAFETY 0.9 / MIN_FACTOR 0.2 / MAX_FACTOR 10, Hairer initial step.

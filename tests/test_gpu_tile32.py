@@ -1,0 +1,89 @@
+"""GPU parity of the 32-row score tile (8 waves) - chosen by the tile rule for 4096 < rows <= 8192 and 12288 < rows:
+score / energy evaluation, the grouped PC sampler at the bench shape (2 x 64 clouds x 50 candidates) and the ODE sampler,
+all against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import genpose_oracle as go
+
+NET_RTOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from genpose_amd.scorenet import ScoreNetHIP
+    return ScoreNetHIP(go.make_state_dict(0, "score"), "cuda"), ScoreNetHIP(go.make_state_dict(0, "energy"), "cuda")
+
+
+@pytest.mark.parametrize("B,K", [(100, 50), (128, 50), (97, 53)])  # 5000 / 6400 / 5141 rows (ragged last tile, 3 clouds per tile)
+def test_score_and_energy_rows(nets, B, K):
+    from genpose_amd import _lib
+    assert _lib.lib().gp_score_tile_rows(B * K) == 32
+    snet, enet = nets
+    gen = torch.Generator().manual_seed(11)
+    pf = torch.randn(B, 1024, generator=gen).abs()
+    pose = torch.randn(B * K, 9, generator=gen)
+    for net, sd, mode, fwd in ((snet, go.make_state_dict(0, "score"), "score", go.score_forward),
+                               (enet, go.make_state_dict(0, "energy"), "energy", go.energy_forward)):
+        for t in (1e-5, 0.4):
+            ref = fwd(sd, pf.repeat_interleave(K, 0), pose, torch.ones(B * K, 1) * t).numpy()
+            cvec = net.cloud_embed(pf.cuda())
+            tvec = net.time_embed(torch.tensor([t], device="cuda"))
+            sigma = torch.tensor([0.01 * 5000.0 ** t], device="cuda")
+            got = net.evaluate(cvec, K, pose.cuda(), tvec[0], sigma, mode).cpu().numpy()
+            np.testing.assert_allclose(got, ref, rtol=NET_RTOL, atol=NET_RTOL * np.abs(ref).max())
+
+
+def test_grouped_pc_sampler_bench_shape(nets):
+    """Two batches of 64 clouds x 50 candidates in one launch chain (6400 rows, 32-row tiles): each batch equals the oracle's
+    PC sampler run on that batch alone (its own batch-mean gradient norm)."""
+    from genpose_amd.samplers import PCSampler
+    snet, _ = nets
+    sd = go.make_state_dict(0, "score")
+    B1, K, n, G = 64, 50, 6, 2
+    R1 = B1 * K
+    gen = torch.Generator().manual_seed(5)
+    pf = torch.randn(G * B1, 1024, generator=gen).abs()
+    centre = torch.randn(G * B1, 3, generator=gen) * 0.3
+    init_x = torch.randn(G * R1, 9, generator=gen) * 50.0
+    init_x[R1:] *= 0.2  # the two batches see very different gradient norms
+    z1, z2 = torch.randn(n, G * R1, 9, generator=gen), torch.randn(n, G * R1, 9, generator=gen)
+    smp = PCSampler(snet, G * B1, K, n, "cuda", use_graph=True, groups=G)
+    assert smp.tile == 32
+    cvec = snet.cloud_embed(pf.cuda())
+    for _ in range(2):
+        _, mean_x = smp.run(cvec, centre.cuda(), init_x.cuda(), z1.cuda(), z2.cuda())
+        torch.cuda.synchronize()
+        got = mean_x.cpu()
+        for g in range(G):
+            rows = slice(g * R1, (g + 1) * R1)
+            feat_rows = pf[g * B1:(g + 1) * B1].repeat_interleave(K, 0)
+            _, ref = go.pc_sampler(lambda x, t: go.score_forward(sd, feat_rows, x, t), init_x[rows], centre[g * B1:(g + 1) * B1].repeat_interleave(K, 0),
+                                   n, z1[:, rows], z2[:, rows])
+            np.testing.assert_allclose(got[rows].numpy(), ref.numpy(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()), err_msg=f"batch {g}")
+
+
+def test_ode_sampler_32_row_tiles(nets):
+    from genpose_amd.samplers import ODESampler
+    snet, _ = nets
+    sd = go.make_state_dict(0, "score")
+    B, K, T0 = 90, 50, 0.3   # 4500 rows
+    from genpose_amd import _lib
+    assert _lib.lib().gp_score_tile_rows(B * K) == 32
+    gen = torch.Generator().manual_seed(9)
+    pf = torch.randn(B, 1024, generator=gen).abs()
+    centre = torch.randn(B, 3, generator=gen) * 0.3
+    init_x = torch.randn(B * K, 9, generator=gen) * float(go.ve_sigma(torch.tensor(T0)))
+    log = []
+    feat_rows = pf.repeat_interleave(K, 0)
+    _, ref, nfev = go.ode_sampler(lambda x, t: go.score_forward(sd, feat_rows, x, t), init_x, centre.repeat_interleave(K, 0), T0, log=log)
+    smp = ODESampler(snet, B, K, "cuda")
+    cvec = snet.cloud_embed(pf.cuda())
+    _, x = smp.run(cvec, centre.cuda(), init_x.cuda(), T0)
+    torch.cuda.synchronize()
+    assert int(smp.last_stats["nfev"]) == nfev
+    scale = max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(x.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-4 * scale)
