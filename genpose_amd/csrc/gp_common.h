@@ -16,7 +16,7 @@ __device__ __forceinline__ void gp_pin(float &v) { asm volatile("" : "+v"(v)); }
 // The stamps stay in registers (struct GpStamps, carried in the trunk's TrunkPre) and are written out once at the end
 // of the kernel: a store per stamp would put an s_waitcnt lgkmcnt(0) - i.e. a drain of all LDS traffic - at every phase edge.
 #ifdef GP_TIMING
-extern __device__ unsigned long long gp_dbg_ts[4 * 32];
+extern __device__ unsigned long long gp_dbg_ts[8 * 32];
 struct GpStamps {
     unsigned long long t[24];
 };

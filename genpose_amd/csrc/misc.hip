@@ -4,7 +4,7 @@
 #include "gp_common.h"
 
 #ifdef GP_TIMING
-__device__ unsigned long long gp_dbg_ts[4 * 32];
+__device__ unsigned long long gp_dbg_ts[8 * 32];
 #endif
 
 extern "C" {
@@ -12,7 +12,7 @@ extern "C" {
 /* tuning builds only: copy the 4x32 phase timestamps of the last instrumented kernel to the host */
 int gp_debug_timestamps(unsigned long long *out) {
 #ifdef GP_TIMING
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gp_dbg_ts), sizeof(unsigned long long) * 128) == hipSuccess ? GP_OK : GP_ELAUNCH;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gp_dbg_ts), sizeof(unsigned long long) * 256) == hipSuccess ? GP_OK : GP_ELAUNCH;
 #else
     (void)out;
     return GP_EINVAL;

@@ -191,6 +191,7 @@ struct SAPreArgs {
     const float *w2, *b2, *w3, *b3;
     float *out;
     int cout_total, cout_off;
+    int groupall;  // np = 1, the neighbourhood is every point of the cloud in order, no centring; tiles combine by atomic max
 };
 
 template <int P>
@@ -203,17 +204,22 @@ __global__ __launch_bounds__(256) void sa_pre_mlp_kernel(SAPreArgs a) {
     float *A = lds, *Bf = lds + P * lda;
     float *dxyz = Bf + P * ldb;            // [P][4]
     int *src = reinterpret_cast<int *>(dxyz + P * 4);  // [P] source point of every row
-    const int nrows = a.np * a.ns;
+    const int nrows = a.groupall ? a.n : a.np * a.ns;
     const float *xyz = a.xyz + (size_t)b * a.n * 3;
     for (int r = tid; r < P; r += 256) {
         int g = row0 + r;
         if (g >= nrows) g = nrows - 1;
-        const int c = g / a.ns;
-        const int j = a.idx[((size_t)b * a.np) * a.ns + g];
-        const float *cp = a.new_xyz + ((size_t)b * a.np + c) * 3;
-        dxyz[r * 4 + 0] = xyz[j * 3 + 0] - cp[0];  // grouped_xyz -= new_xyz (pointnet2_utils.py:253)
-        dxyz[r * 4 + 1] = xyz[j * 3 + 1] - cp[1];
-        dxyz[r * 4 + 2] = xyz[j * 3 + 2] - cp[2];
+        int j = g;
+        float cx = 0.f, cy = 0.f, cz = 0.f;  // GroupAll keeps absolute coordinates (pointnet2_utils.py:281-289)
+        if (!a.groupall) {
+            const int c = g / a.ns;
+            j = a.idx[((size_t)b * a.np) * a.ns + g];
+            const float *cp = a.new_xyz + ((size_t)b * a.np + c) * 3;
+            cx = cp[0], cy = cp[1], cz = cp[2];
+        }
+        dxyz[r * 4 + 0] = xyz[j * 3 + 0] - cx;  // grouped_xyz -= new_xyz (pointnet2_utils.py:253)
+        dxyz[r * 4 + 1] = xyz[j * 3 + 1] - cy;
+        dxyz[r * 4 + 2] = xyz[j * 3 + 2] - cz;
         dxyz[r * 4 + 3] = 0.f;
         src[r] = j;
     }
@@ -249,8 +255,8 @@ __global__ __launch_bounds__(256) void sa_pre_mlp_kernel(SAPreArgs a) {
     l3.n = a.n, l3.np = a.np, l3.ns = a.ns, l3.cin = 0, l3.c1 = a.c1, l3.c2 = a.c2, l3.c3 = a.c3;
     l3.xyz = nullptr, l3.feats_in = nullptr, l3.new_xyz = nullptr, l3.idx = nullptr;
     l3.w1 = l3.b1 = l3.w2 = l3.b2 = nullptr, l3.w3 = a.w3, l3.b3 = a.b3;
-    l3.out = a.out, l3.cout_total = a.cout_total, l3.cout_off = a.cout_off, l3.groupall = 0;
-    const int wn = pick_wn(gp_round16(a.c3) / 16, P, a.ns);
+    l3.out = a.out, l3.cout_total = a.cout_total, l3.cout_off = a.cout_off, l3.groupall = a.groupall;
+    const int wn = pick_wn(gp_round16(a.c3) / 16, P, a.groupall ? 16 : a.ns);
     if constexpr (P >= 64) {
         if (wn == 1) return layer3_max<P / 64, 1>(l3, A, lda, c2p, row0, b);
     }
@@ -270,7 +276,7 @@ int launch_pre(const SAPreArgs &a, int b, hipStream_t st) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return GP_ELAUNCH;
     }
-    const int nrows = a.np * a.ns;
+    const int nrows = a.groupall ? a.n : a.np * a.ns;
     hipLaunchKernelGGL(kern, dim3((nrows + P - 1) / P, b), dim3(256), lds, st, a);
     return gp_launch_status();
 }
@@ -836,11 +842,17 @@ int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, cons
                       const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2, const float *bias2,
                       const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s) {
     if (b < 0 || n <= 0 || np <= 0 || ns <= 0 || c1 <= 0 || c2 <= 0 || c3 <= 0) return GP_EINVAL;
-    if (!xyz || !new_xyz || !idx || !wxyz || !bias1 || !wpack2 || !bias2 || !wpack3 || !bias3 || !out) return GP_EINVAL;
-    if ((ns % 16) != 0 || ns > 64 || (cout_total & 3) || (cout_off & 3) || (c3 & 3) || cout_off + c3 > cout_total) return GP_EINVAL;
+    if (!xyz || !wxyz || !bias1 || !wpack2 || !bias2 || !wpack3 || !bias3 || !out) return GP_EINVAL;
+    const bool groupall = !idx && !new_xyz;  // GroupAll level: one neighbourhood = all n points
+    if (!groupall && (!idx || !new_xyz)) return GP_EINVAL;
+    if (groupall && (np != 1 || ns != n)) return GP_EINVAL;
+    if (!groupall && ((ns % 16) != 0 || ns > 64)) return GP_EINVAL;
+    if ((cout_total & 3) || (cout_off & 3) || (c3 & 3) || cout_off + c3 > cout_total) return GP_EINVAL;
     if (z && ((zstride & 3) || (zoff & 3) || zoff + c1 > zstride)) return GP_EINVAL;
     if (b == 0) return GP_OK;
-    SAPreArgs a{n, np, ns, c1, c2, c3, zstride, zoff, xyz, new_xyz, z, idx, wxyz, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off};
+    SAPreArgs a{n, np, ns, c1, c2, c3, zstride, zoff, xyz, new_xyz, z, idx, wxyz, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off,
+                groupall ? 1 : 0};
+    if (groupall) return launch_pre<32>(a, b, (hipStream_t)s);
     static int nochain = -1;  // GP_SA_NOCHAIN=1 forces the tile kernel (tuning / A-B tests)
     if (nochain < 0) nochain = getenv("GP_SA_NOCHAIN") ? 1 : 0;
     if (!z && !nochain) {

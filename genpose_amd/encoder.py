@@ -3,8 +3,9 @@
 forward(pts [B,N,3] f32 on the GPU) -> [B,1024].  Launch sequence per call (all on torch's current stream):
   1 x gp_fps_chain      FPS + gather for every level (one workgroup per cloud)
   L x gp_ball_query_msg both radii of a level in one pass
-  2L x gp_sa_mlp_max    gather -> 3-layer MLP on fp32 MFMA -> max-pool, per scale
-  2 x gp_sa_mlp_max     GroupAll level (integer atomic max into a zeroed buffer)
+  L x gp_point_linear   hoisted feature half of the first layer, once per source point (both scales)
+  2L x gp_sa_pre_mlp_max gather -> xyz half of layer 1 -> layers 2-3 on fp32 MFMA -> max-pool, per scale
+  1 + 2 x the same pair  GroupAll level (tiles of a cloud combine by integer atomic max into a zeroed buffer)
 Intermediate features stay point-major [B, n, C]; the reference's grouped [B,C+3,np,ns] tensors never exist.
 """
 import ctypes
@@ -38,6 +39,7 @@ class Pointnet2EncoderHIP:
             cout = sum(s.couts[-1] for s in self.w.levels[k])
             if npnt is None:
                 ws["feat"].append(torch.zeros(B, 1, cout, device=dev))
+                ws["z"].append(torch.empty(B, n, sum(s.couts[0] for s in self.w.levels[k]), device=dev) if cin > 0 else None)
                 break
             ws["fps_idx"].append(torch.empty(B, npnt, dtype=torch.int32, device=dev))
             ws["new_xyz"].append(torch.empty(B, npnt, 3, device=dev))
@@ -80,13 +82,20 @@ class Pointnet2EncoderHIP:
             out = ws["feat"][k]
             cout_total = out.shape[-1]
             if npnt is None:
+                # GroupAll: same hoisted form - layer 1's feature half is one GEMM over all B*n points (both scales), the
+                # tiles of a cloud combine through an integer atomic max into the zeroed output
                 out.zero_()
-                off = 0
+                z = ws["z"][k]
+                zstride = sum(sc.couts[0] for sc in scales)
+                if z is not None:
+                    _lib.call("gp_point_linear", B * n, cin, zstride, ptr(feats), ptr(self.w.z_weights[k]), ptr(z), st)
+                off, zoff = 0, 0
                 for sc in scales:
                     (w1, b1), (w2, b2), (w3, b3) = sc.layers
-                    _lib.call("gp_sa_mlp_max", B, n, 1, n, cin, sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(feats), None, None,
-                              ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out), cout_total, off, st)
+                    _lib.call("gp_sa_pre_mlp_max", B, n, 1, n, sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), None, None, ptr(z), zstride,
+                              zoff, ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out), cout_total, off, st)
                     off += sc.couts[2]
+                    zoff += sc.couts[0]
                 feats, n, cin = out, 1, cout_total
                 break
             new_xyz = ws["new_xyz"][k]

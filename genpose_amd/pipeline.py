@@ -17,7 +17,7 @@ class PipelinedPCPredictor:
     score_agent : genpose_amd.posenet_agent.PoseNet (weights loaded, sampler_mode ['pc'])
     """
 
-    def __init__(self, score_agent, B, K, num_steps, depth=2, sampler_streams=1, batches_per_launch=1):
+    def __init__(self, score_agent, B, K, num_steps, depth=2, sampler_streams=1, batches_per_launch=1, overlap=True):
         """batches_per_launch = G > 1: G consecutive batches share every encoder and sampler launch (the batch-global
         coupling of the sampler stays per batch - gp_pc_step_grouped); at B*K = 3200 rows this lets the sampler run on
         32-row tiles (MFMA-bound) instead of 16-row tiles (weight-stream-bound): 21 vs 26 us per batch and step."""
@@ -34,7 +34,7 @@ class PipelinedPCPredictor:
         self.s_enc = torch.cuda.Stream(self.dev, priority=0)
         # (sampler_streams > 1 puts several sampler chains in flight; measured SLOWER at the bench configuration:
         #  13.1 k vs 14.2 k poses/s - the chains contend for the same MFMA pipes and each step boundary gets longer)
-        self.s_smp = [torch.cuda.Stream(self.dev, priority=-1) for _ in range(sampler_streams)]
+        self.s_smp = [torch.cuda.Stream(self.dev, priority=-1) for _ in range(sampler_streams)] if overlap else [self.s_enc]
         self.smp = [{self.G: PCSampler(self.net.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False, groups=self.G)}
                     for _ in range(sampler_streams)]
         self.timing = False

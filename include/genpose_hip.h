@@ -101,8 +101,9 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
  * gp_point_linear computes z[row, 0:n_out] = x[row, 0:k_in] . W1f^T once per SOURCE point (rows = b*n; wpack from gp_pack_weight);
  * gp_sa_pre_mlp_max then gathers z rows (channels [zoff, zoff+c1) of a zstride-wide row; z = NULL for a level without input
  * features), adds wxyz[c][0..2].(xyz_j - centre) + bias1[c], ReLU, and runs layers 2, 3 + max-pool as gp_sa_mlp_max does.
- * wxyz is [round16(c1)][4] (x, y, z, 0), BN scale folded in.  This is the encoder's production path; gp_sa_mlp_max remains for
- * the GroupAll level and as the unhoisted form. */
+ * wxyz is [round16(c1)][4] (x, y, z, 0), BN scale folded in.  new_xyz = idx = NULL with np = 1, ns = n selects GroupAll
+ * (every point once, absolute xyz; out must be zeroed first - the tiles of a cloud combine by integer atomic max).
+ * This is the encoder's production path for every level; gp_sa_mlp_max remains as the unhoisted form. */
 int gp_point_linear(int rows, int k_in, int n_out, const float *x, const float *wpack, float *z, gp_stream_t s);
 int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz, const int32_t *idx,
                       const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2, const float *bias2,

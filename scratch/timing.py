@@ -13,11 +13,12 @@ x0 = torch.randn(B * K, 9, device="cuda") * 50
 for _ in range(3): smp.run(cvec, cen, x0)
 torch.cuda.synchronize()
 l = _lib.lib(); l.gp_debug_timestamps.argtypes = [ctypes.c_void_p]
-buf = (ctypes.c_ulonglong * 128)()
+buf = (ctypes.c_ulonglong * 256)()
 assert l.gp_debug_timestamps(buf) == 0
-ts = np.array(buf, dtype=np.uint64).reshape(4, 32).astype(np.int64)
+ts = np.array(buf, dtype=np.uint64).reshape(8, 32).astype(np.int64)
 names = {0: "start", 19: "loads+gn", 1: "prologue done", 2: "trunk in", 3: "L1 done(+bar)", 4: "L2 mfma+epi", 5: "L2 barrier", 6: "h0 start", 7: "h0 mfma", 8: "h0 epi",
          9: "h1 start", 10: "h1 mfma", 11: "h1 epi", 12: "h2 start", 13: "h2 mfma", 14: "h2 epi", 16: "trunk out", 17: "end"}
-for w in range(4):
+for w in range(8):
+    if ts[w, 0] == 0: continue
     t0 = ts[w, 0]
     print(f"wave {w}: " + "  ".join(f"{names[i]}={ts[w, i] - t0}" for i in sorted(names) if ts[w, i] > 0))
