@@ -67,9 +67,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GP_BENCH_FORCE_DIST") == "1":  # GP_BENCH_FORCE_DIST: exercise RCCL with one rank (self-test)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if one_dev:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
