@@ -52,6 +52,27 @@ class SingleFrameRunner:
         return {k: v.cpu().numpy() for k, v in self.infer_tensors(clouds).items()}
 
 
+    def evaluate(self, detect_result, out_dir=None, degree_thresholds=tuple(range(0, 46)), shift_thresholds=tuple(i / 2 for i in range(21)),
+                 iou_thresholds=tuple(i / 100 for i in range(101)), pooling_mode="average", ranker="energy_ranker"):
+        """inference_pose -> inference_energy -> evaluate (evaluation_single.py:356-544) on the reference's `detect_result` dict
+        (img_path -> {'result', 'valid_pts', 'cat_id', 'valid_inst'}, what detect_mrcnn_genpose pickles): fills every valid
+        instance's K hypotheses (ranked by energy, as pred_energy_batch stores them) and energies in place, then computes mAP
+        with the reference's threshold grids.  Returns (iou_aps, pose_aps, iou_acc, pose_acc, store)."""
+        from . import evaluation
+        if self.energy_agent is None:
+            raise ValueError("evaluation needs the energy agent (hypotheses are ranked by energy)")
+        store = evaluation.DetectionResults(detect_result, self.repeat_num)
+        for cat in store.by_category:
+            for sl, pts in store.batches(cat, self.batch_size):
+                res = self.infer(pts)
+                sorted_energy = -np.sort(-res["energy"], axis=1)  # sort_poses_by_energy's second output (reward.py:146-147)
+                store.write(cat, sl, res["sorted_RTs"], sorted_energy)
+        maps = evaluation.compute_mAP(store.results(), out_dir, list(degree_thresholds), list(shift_thresholds), list(iou_thresholds),
+                                      iou_pose_thres=0.1, use_matches_for_pose=True, repeat_num=self.repeat_num, pooling_mode=pooling_mode,
+                                      ratio=self.ratio, ranker=ranker)
+        return maps + (store,)
+
+
 # ------------------------------------------------------------------ tracking
 def _unit(q):
     return q / q.norm(dim=-1, keepdim=True)

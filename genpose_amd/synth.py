@@ -140,3 +140,74 @@ def golden_tracking_gt(n_obj=2):
         RT[o, :3, :3] = _rand_rot(rng)
         RT[o, :3, 3] = frames0[o].mean(0)
     return RT
+
+
+def golden_map_results(seed=77, n_images=12, K=10):
+    """Synthetic per-image detection + multi-hypothesis pose results in the reference's container layout (the dicts that
+    evaluation_single.py:505-518 hands to compute_mAP): ground truth with NOCS-style scaled sRT, 2-D boxes, mug handle
+    visibility; detections with missed / spurious / mis-classified instances; K pose hypotheses per detection scattered
+    around the truth with energies that correlate with their quality."""
+    rng = np.random.default_rng(seed)
+
+    def rot_about(axis, deg):
+        a = np.asarray(axis, dtype=np.float64)
+        a = a / np.linalg.norm(a)
+        t = np.deg2rad(deg)
+        Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(t) * Kx + (1 - np.cos(t)) * (Kx @ Kx)
+
+    results = []
+    for _ in range(n_images):
+        n_gt = int(rng.integers(0, 6))
+        gt_cls = rng.integers(1, 7, size=n_gt).astype(np.int32)
+        gt_RTs = np.tile(np.eye(4), (n_gt, 1, 1))
+        gt_boxes = np.zeros((n_gt, 4), dtype=np.int32)
+        for g in range(n_gt):
+            R = _rand_rot(rng).astype(np.float64)
+            gt_RTs[g, :3, :3] = R * rng.uniform(0.1, 0.4)
+            gt_RTs[g, :3, 3] = [rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(0.5, 1.2)]
+            y1, x1 = int(rng.integers(0, 300)), int(rng.integers(0, 450))
+            gt_boxes[g] = [y1, x1, y1 + int(rng.integers(40, 160)), x1 + int(rng.integers(40, 160))]
+        hv = rng.integers(0, 2, size=n_gt).astype(np.int32)
+        pc, pb, ps, hyp, en = [], [], [], [], []
+        for g in range(n_gt):
+            if rng.random() > 0.85:
+                continue  # missed
+            cls = int(gt_cls[g]) if rng.random() < 0.9 else int(rng.integers(1, 7))
+            jit = rng.integers(-12, 13, size=4)
+            pc.append(cls)
+            pb.append(gt_boxes[g] + jit)
+            ps.append(rng.uniform(0.3, 1.0))
+            Rg = gt_RTs[g, :3, :3] / np.cbrt(np.linalg.det(gt_RTs[g, :3, :3]))
+            h = np.tile(np.eye(4), (K, 1, 1))
+            e = np.zeros((K, 2))
+            spread = rng.choice([2.0, 6.0, 20.0])
+            for k in range(K):
+                ang = abs(rng.normal(0, spread)) if rng.random() < 0.85 else rng.uniform(30, 180)
+                Rk = rot_about(rng.normal(size=3), ang) @ Rg
+                if cls in (1, 2, 4):
+                    Rk = Rk @ rot_about([0, 1, 0], rng.uniform(0, 360))  # free spin about the symmetry axis
+                dt = rng.normal(0, 0.01 * spread / 2.0, size=3)
+                h[k, :3, :3] = Rk
+                h[k, :3, 3] = gt_RTs[g, :3, 3] + dt
+                e[k] = [-ang + rng.normal(0, 3.0), -100 * np.linalg.norm(dt) + rng.normal(0, 1.0)]
+            hyp.append(h)
+            en.append(e)
+        for _f in range(int(rng.integers(0, 3))):  # spurious detections
+            pc.append(int(rng.integers(1, 7)))
+            y1, x1 = int(rng.integers(0, 300)), int(rng.integers(0, 450))
+            pb.append(np.array([y1, x1, y1 + 80, x1 + 80]))
+            ps.append(rng.uniform(0.05, 0.6))
+            h = np.tile(np.eye(4), (K, 1, 1))
+            for k in range(K):
+                h[k, :3, :3] = _rand_rot(rng)
+                h[k, :3, 3] = [rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(0.5, 1.2)]
+            hyp.append(h)
+            en.append(rng.normal(size=(K, 2)))
+        n_p = len(pc)
+        results.append({
+            "gt_class_ids": gt_cls, "gt_bboxes": gt_boxes, "gt_RTs": gt_RTs, "gt_scales": np.ones((n_gt, 3)), "gt_handle_visibility": hv,
+            "pred_class_ids": np.array(pc, dtype=np.int32), "pred_bboxes": np.array(pb, dtype=np.int32).reshape(n_p, 4),
+            "pred_scores": np.array(ps, dtype=np.float64), "pred_RTs": np.tile(np.eye(4), (n_p, 1, 1)), "pred_scales": np.ones((n_p, 3)),
+            "multi_hypothesis_pred_RTs": np.array(hyp).reshape(n_p, K, 4, 4), "energy": np.array(en).reshape(n_p, K, 2)})
+    return results

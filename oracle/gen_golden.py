@@ -255,5 +255,45 @@ def _cal_average(ns, RTs, sel):
     return torch.from_numpy(avg).float()
 
 
+def main_g10():
+    """G10 mAP evaluation: the reference's compute_mAP (utils/sgpa_utils.py:957-1183) with the threshold grids of
+    evaluate() (runners/evaluation_single.py:493-495, 538-542) on synthetic detection / multi-hypothesis results."""
+    import copy
+    import tempfile
+    from genpose_amd import synth
+    ns = ref_import.load()
+    K = 10
+    results = synth.golden_map_results(77, 12, K)
+    degree = list(range(0, 46, 1))
+    shift = [i / 2 for i in range(21)]
+    iou = [i / 100 for i in range(101)]
+    g10 = {"K": np.array(K)}
+    torch.Tensor.cuda = lambda self, *a, **k: self  # sort_sRT_by_energy moves its quaternions to the GPU (sgpa_utils.py:938)
+    try:
+        for mode in ("average", "nearest"):
+            with tempfile.TemporaryDirectory() as d:
+                iou_aps, pose_aps, iou_acc, pose_acc = ns.sgpa.compute_mAP(
+                    copy.deepcopy(results), d, degree, shift, iou, iou_pose_thres=0.1, use_matches_for_pose=True, repeat_num=K,
+                    pooling_mode=mode, ratio=0.6, so3_vis=False, ranker="energy_ranker")
+            g10[f"{mode}_iou_aps"], g10[f"{mode}_pose_aps"] = iou_aps, pose_aps
+            g10[f"{mode}_iou_acc"], g10[f"{mode}_pose_acc"] = iou_acc, pose_acc
+        # building blocks on the first image with >= 2 ground-truth objects and >= 2 detections
+        r = next(x for x in results if len(x["gt_class_ids"]) >= 2 and len(x["pred_class_ids"]) >= 2)
+        gm, pm, ov, idx = ns.sgpa.compute_2d_IoU_matches(r["gt_class_ids"], r["gt_bboxes"], r["pred_class_ids"], r["pred_bboxes"],
+                                                        r["pred_scores"], iou)
+        g10["blk_gt_matches"], g10["blk_pred_matches"], g10["blk_overlaps"], g10["blk_indices"] = gm, pm, ov, idx
+        sel, avg, sel_e = ns.sgpa.sort_sRT_by_energy(r["multi_hypothesis_pred_RTs"].copy(), r["energy"].copy(), None, "energy_ranker", 0.6, "average")
+        g10["blk_selected"], g10["blk_average"], g10["blk_selected_energy"] = sel, avg, sel_e
+        syn = ["BG", "bottle", "bowl", "camera", "can", "laptop", "mug"]
+        rt = ns.sgpa.compute_RT_overlaps(r["gt_class_ids"], r["gt_RTs"], r["gt_handle_visibility"], r["pred_class_ids"], avg, syn)
+        g10["blk_RT_overlaps"] = rt
+        pgm, ppm = ns.sgpa.compute_RT_matches(rt, r["pred_class_ids"], r["gt_class_ids"], degree + [360], shift + [100])
+        g10["blk_pose_gt_matches"], g10["blk_pose_pred_matches"] = pgm, ppm
+    finally:
+        del torch.Tensor.cuda
+    np.savez_compressed(os.path.join(OUT, "g10_map.npz"), **g10)
+    print("g10_map.npz", os.path.getsize(os.path.join(OUT, "g10_map.npz")))
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main_g10() if "--g10" in sys.argv else main())

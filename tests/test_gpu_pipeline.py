@@ -72,3 +72,47 @@ def test_grouped_tile_rule():
     assert l.gp_pc_tile_rows(2, 3, 10) == 16 or l.gp_pc_tile_rows(2, 3, 10) < 0  # 30 rows per batch: no tile divides it
     assert l.gp_pc_tile_rows(2, 3, 10) < 0
     assert l.gp_pc_tile_rows(2, 8, 10) == 16       # 80 rows per batch
+
+
+def test_runner_evaluate_end_to_end(tmp_path):
+    """detect_result dict -> per-category batches -> score + energy agents -> hypotheses written back by (image, instance)
+    -> mAP (SURVEY §8f row 2 on top of the hot path).  Ground truth is set to each instance's own aggregated prediction, so
+    every matched detection must count at every threshold above the numerical floor."""
+    from genpose_amd import evaluation, synth
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.runner import SingleFrameRunner
+    K = 6
+    sa = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"]))
+    sa.load_state_dict(go.make_state_dict(0, "score"))
+    ea = PoseNet(get_config(posenet_mode="energy"))
+    ea.load_state_dict(go.make_state_dict(0, "energy"))
+    runner = SingleFrameRunner(sa, ea, repeat_num=K, T0=0.3, batch_size=3)
+    clouds = synth.make_batch(5, start=40)
+    cats = [5, 5, 2, 0, 5]  # indices into ('bottle','bowl','camera','can','laptop','mug') -> class ids 6,6,3,1,6
+    det = {}
+    for img, members in (("img0", [0, 2, 3]), ("img1", [1, 4])):
+        n = len(members) + 1  # one extra detection without a valid cloud (stays at identity)
+        boxes = np.array([[10 + 60 * i, 20, 60 + 60 * i, 90] for i in range(n)], dtype=np.int32)
+        cls = np.array([cats[m] + 1 for m in members] + [3], dtype=np.int32)
+        det[img] = {"result": {"pred_RTs": np.tile(np.eye(4), (n, 1, 1)), "pred_scales": np.ones((n, 3)), "pred_class_ids": cls,
+                               "pred_bboxes": boxes, "pred_scores": np.linspace(0.9, 0.5, n),
+                               "gt_class_ids": cls[:-1].copy(), "gt_bboxes": boxes[:-1].copy(), "gt_RTs": np.tile(np.eye(4), (n - 1, 1, 1)),
+                               "gt_scales": np.ones((n - 1, 3)), "gt_handle_visibility": np.ones(n - 1, dtype=np.int32)},
+                    "valid_pts": [clouds[m] for m in members], "valid_rgb": None, "cat_id": [cats[m] for m in members],
+                    "valid_inst": list(range(len(members)))}
+    torch.manual_seed(0)
+    iou_aps, pose_aps, iou_acc, pose_acc, store = runner.evaluate(det, str(tmp_path))
+    for img in det:
+        r = det[img]["result"]
+        assert np.allclose(r["multi_hypothesis_pred_RTs"][-1], np.eye(4)) and np.all(r["energy"][-1] == 0)  # invalid instance untouched
+        assert not np.allclose(r["multi_hypothesis_pred_RTs"][0, 0], np.eye(4))
+        assert np.all(np.diff(r["energy"][:-1], axis=1) <= 0)  # stored energies are ranked
+        # ground truth := the aggregate of what was stored -> zero pose error by construction
+        _, avg, _ = evaluation.sort_sRT_by_energy(r["multi_hypothesis_pred_RTs"][:-1], r["energy"][:-1], None, "energy_ranker", 0.6, "average")
+        r["gt_RTs"] = avg
+    deg, sh, iou = [1, 5], [1, 5], [0.1, 0.5]
+    iou_aps, pose_aps, iou_acc, pose_acc = evaluation.compute_mAP(store.results(), None, deg, sh, iou, iou_pose_thres=0.1,
+                                                                   use_matches_for_pose=True, repeat_num=K, ratio=0.6)
+    for c in (1, 3, 6):  # classes present
+        assert pose_aps[c, 0, 0] == 1.0 and iou_aps[c, 0] > 0.0, (c, pose_aps[c], iou_aps[c])
