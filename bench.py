@@ -198,6 +198,31 @@ def main():
         st = score_agent.net._samplers[("ode", B, K)].last_stats
         nfev = int(st["nfev"])
 
+    # the same workload with ONE batch per launch (no request batching), reported next to the headline for comparison
+    one_batch = None
+    if pipelined and G > 1 and world == 1:
+        from genpose_amd.pipeline import PipelinedPCPredictor
+        p1 = PipelinedPCPredictor(score_agent, B, K, n, batches_per_launch=1, overlap=False)
+        p1.run([pts] * 3)
+        torch.cuda.synchronize()
+        nb = 10
+        t1 = time.perf_counter()
+        p1.run([pts] * nb)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        smp1 = p1._sampler(0, 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            smp1.graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        l1 = e0.elapsed_time(e1) * 1e-3 / (5 * (n + 1))
+        one_batch = {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "kernel": f"pc_step_kernel<{smp1.tile}>",
+                     "rows_per_launch": B * K, "avg_launch_us": round(l1 * 1e6, 2),
+                     "frac": round(B * K * FLOP_SCORE_ROW / l1 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        del p1, smp1
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args, K, n)
@@ -217,7 +242,7 @@ def main():
                        "weights": "seeded random (reference state-dict schema)", "parallelism": f"clouds sharded x{world}"},
             "whole_path_tflops": round(value * flop_per_pose / 1e12, 2),
             "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "one_batch_per_launch": one_batch,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
