@@ -47,6 +47,8 @@ SIGNATURES = {
     "gp_time_embed": [c_int, NETP, P, P, P],
     "gp_score_eval": [c_int, c_int, NETP, P, P, P, P, c_int, P, P],
     "gp_pc_step": [c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
+    "gp_roi_to_cloud": [c_int, c_int, c_int, c_int, P, P, P, c_float, c_float, c_float, c_float, P, P, P, P],
+    "gp_cloud_sample": [c_int, c_int, c_int, P, P, P, P, P],
     "gp_pc_tile_rows": [c_int, c_int, c_int],
     "gp_pc_step_grouped": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
     "gp_rk45_state_bytes": [],

@@ -211,3 +211,34 @@ def golden_map_results(seed=77, n_images=12, K=10):
             "pred_scores": np.array(ps, dtype=np.float64), "pred_RTs": np.tile(np.eye(4), (n_p, 1, 1)), "pred_scales": np.ones((n_p, 3)),
             "multi_hypothesis_pred_RTs": np.array(hyp).reshape(n_p, K, 4, 4), "energy": np.array(en).reshape(n_p, K, 2)})
     return results
+
+
+def golden_depth_frame(seed=5, n_inst=6, H=480, W=640):
+    """A synthetic REAL275-like frame for the depth -> cloud pre-processing: uint16 depth in mm (a tilted background plane
+    with holes, elliptical objects in front of it), Mask-RCNN style outputs masks [H,W,n] bool, rois [n,4] (y1,x1,y2,x2),
+    class_ids [n] (1..6).  Instances: large (> 1024 pixels), small (< 1024), touching the image border, an empty mask and a
+    mask that lies on a depth hole (both skipped by the reference)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    depth = (900 + 0.4 * xx + 0.7 * yy).astype(np.float64)
+    holes = rng.random((H, W)) < 0.03
+    masks = np.zeros((H, W, n_inst), dtype=bool)
+    rois = np.zeros((n_inst, 4), dtype=np.int32)
+    specs = [(240, 320, 70, 90), (100, 520, 2, 3), (30, 40, 45, 60), (455, 610, 40, 50), (300, 100, 0, 0), (200, 200, 20, 20)]
+    for i in range(n_inst):
+        cy, cx, ry, rx = specs[i % len(specs)]
+        if ry == 0:
+            rois[i] = [cy - 5, cx - 5, cy + 5, cx + 5]  # detector box without mask pixels
+            continue
+        m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        masks[:, :, i] = m
+        obj = 600 + 40 * i + 30 * np.sqrt(np.clip(1 - ((yy - cy) / ry) ** 2 - ((xx - cx) / rx) ** 2, 0, 1))
+        if i % len(specs) == 5:
+            depth[m] = 0  # sensor hole over the whole object
+        else:
+            depth[m] = obj[m]
+        ys, xs = np.where(m)
+        rois[i] = [max(ys.min() - 3, 0), max(xs.min() - 3, 0), min(ys.max() + 3, H - 1), min(xs.max() + 3, W - 1)]
+    depth[holes] = 0
+    class_ids = (np.arange(n_inst) % 6 + 1).astype(np.int32)
+    return depth.astype(np.uint16), masks, rois, class_ids

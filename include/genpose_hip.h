@@ -32,6 +32,22 @@ extern "C" {
 
 typedef void *gp_stream_t; /* hipStream_t */
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * E. Depth + instance mask -> point clouds (the step right before the path).
+ * Replaces the per-detection body of detect_mrcnn_genpose (runners/evaluation_single.py:162-216):
+ *   crop_resize_by_warp_affine(INTER_NEAREST) of raw depth, mask & (depth > 0) and the pixel-coordinate map
+ *   (utils/datasets_utils.py:82-94; OpenCV's 10-bit fixed-point nearest sampling), depth_to_pcl (:107-118, float32) on the
+ *   pixels with depth > 0 inside the mask, in raster order of the img x img crop, divided by 1000 (metres).
+ *   depth [h,w] uint16 mm; masks [h,w,ninst] uint8 (Mask-RCNN layout); minv [ninst][6] = the INVERSE of the 2x3 matrix that
+ *   get_affine_transform (:96-136) builds from get_bbox's window (doubles, row major): source = minv . (x, y, 1);
+ *   pcl [ninst][img*img][3] f32 (first count[i] rows written); count / depth_count [ninst] = number of valid masked pixels /
+ *   of crop pixels with a depth reading (the reference skips an instance when either is <= 1, :201-208).
+ * gp_cloud_sample = sample_points (:120-133): out[i][k] = pcl[i][k % count] when count <= npts (tiling), else pcl[i][ids[i][k]]
+ *   (ids = first npts entries of a permutation of count, drawn by the caller; NULL -> the first npts rows). */
+int gp_roi_to_cloud(int h, int w, int ninst, int img, const uint16_t *depth, const uint8_t *masks, const double *minv, float fx, float fy,
+                    float cx, float cy, float *pcl, int32_t *count, int32_t *depth_count, gp_stream_t s);
+int gp_cloud_sample(int ninst, int cap, int npts, const float *pcl, const int32_t *count, const int32_t *ids, float *out, gp_stream_t s);
+
 /* Library / device identification: returns ABI version; writes gcnArchName of the current device. */
 int gp_version(void);
 int gp_device_arch(char *buf, int buflen);

@@ -295,5 +295,54 @@ def main_g10():
     print("g10_map.npz", os.path.getsize(os.path.join(OUT, "g10_map.npz")))
 
 
+def main_g11():
+    """G11 depth + mask -> cloud: the importable reference pieces (get_bbox, get_2d_coord_np, crop_resize_by_warp_affine /
+    get_affine_transform on the shimmed cv2) composed exactly as detect_mrcnn_genpose does (evaluation_single.py:165-216);
+    depth_to_pcl / sample_points are nested functions there and come from oracle/preprocess_oracle.py."""
+    from genpose_amd import synth
+    from oracle import preprocess_oracle as po
+    ns = ref_import.load()
+    sys.path.insert(0, ref_import.REF)
+    from utils import datasets_utils as du
+    import cv2  # the shim
+    depth, masks, rois, class_ids = synth.golden_depth_frame()
+    K = po.REAL_INTRINSICS
+    g = {"intrinsics": K}
+    im_H, im_W = depth.shape
+    for i in range(len(class_ids)):
+        rmin, rmax, cmin, cmax = ns.sgpa.get_bbox(rois[i])
+        assert (rmin, rmax, cmin, cmax) == po.get_bbox(rois[i])
+        g[f"i{i}_bbox"] = np.array([rmin, rmax, cmin, cmax])
+        mask = np.logical_and(masks[:, :, i], depth > 0)
+        coord_2d = du.get_2d_coord_np(im_W, im_H).transpose(1, 2, 0)
+        x1, y1, x2, y2 = cmin, rmin, cmax, rmax
+        center = np.array([0.5 * (x1 + x2), 0.5 * (y1 + y2)])
+        scale = min(max(y2 - y1, x2 - x1), max(im_H, im_W)) * 1.0
+        roi_coord = du.crop_resize_by_warp_affine(coord_2d, center, scale, 256, interpolation=cv2.INTER_NEAREST).transpose(2, 0, 1)
+        roi_mask = du.crop_resize_by_warp_affine(mask.copy().astype(np.float32), center, scale, 256, interpolation=cv2.INTER_NEAREST)
+        roi_depth = du.crop_resize_by_warp_affine(depth, center, scale, 256, interpolation=cv2.INTER_NEAREST)
+        g[f"i{i}_roi_depth_sum"] = np.array(int(roi_depth.astype(np.int64).sum()))
+        g[f"i{i}_roi_mask_sum"] = np.array(int(roi_mask.sum()))
+        g[f"i{i}_roi_coord_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(roi_coord).tobytes()).digest(), dtype=np.uint8)
+        valid = ((roi_depth.reshape(-1).astype(np.float32) > 0) * roi_mask.reshape(-1)) > 0
+        g[f"i{i}_n_valid"] = np.array(int(valid.sum()))
+        cloud = po.instance_cloud(depth, masks[:, :, i], rois[i], K)
+        if cloud is None:
+            assert np.sum(roi_depth > 0) <= 1 or valid.sum() <= 1
+            continue
+        # the oracle's crop equals the reference functions' crop
+        assert cloud.shape[0] == int(valid.sum())
+        d = roi_depth.reshape(-1).astype(np.float32)[valid]
+        assert np.array_equal(cloud[:, 2], d / np.float32(1000.0))
+        assert np.array_equal(cloud[:, 0], ((roi_coord[0].reshape(-1)[valid] - K[0, 2]) * d / K[0, 0]) / np.float32(1000.0))
+        g[f"i{i}_cloud_head"] = cloud[:64]
+        g[f"i{i}_cloud_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(cloud).tobytes()).digest(), dtype=np.uint8)
+    rs = np.random.RandomState(11)
+    pts, cat, inst = po.frame_clouds(depth, masks, rois, class_ids, K, rng=rs)
+    g["points"], g["cat_id"], g["valid_inst"] = pts, np.array(cat), np.array(inst)
+    np.savez_compressed(os.path.join(OUT, "g11_preprocess.npz"), **g)
+    print("g11_preprocess.npz", os.path.getsize(os.path.join(OUT, "g11_preprocess.npz")))
+
+
 if __name__ == "__main__":
-    sys.exit(main_g10() if "--g10" in sys.argv else main())
+    sys.exit(main_g11() if "--g11" in sys.argv else (main_g10() if "--g10" in sys.argv else main()))
