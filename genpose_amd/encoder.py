@@ -26,8 +26,8 @@ class Pointnet2EncoderHIP:
         self._ws = {}
 
     # ------------------------------------------------------------------ workspace (cached per batch/size)
-    def _workspace(self, B, N):
-        key = (B, N)
+    def _workspace(self, B, N, slot=0):
+        key = (B, N, slot)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
@@ -51,17 +51,20 @@ class Pointnet2EncoderHIP:
         self._ws[key] = ws
         return ws
 
-    def forward(self, pts, return_intermediates=False):
+    def sample_centres(self, pts, slot=0):
+        """Stage 1 of forward(): furthest point sampling + gather for every level into workspace `slot` (launches on the
+        current stream).  Latency-bound and light (one workgroup per cloud), so a pipeline can run it for the NEXT batch on a
+        side stream while the MFMA-heavy stages of the current one own the chip; forward(..., slot=slot, centres_done=True)
+        then skips it."""
         _lib.check_device()
         if not pts.is_cuda or pts.dtype != torch.float32:
             raise RuntimeError("pts must be a float32 CUDA tensor")
         xyz0 = pts[..., 0:3].contiguous()
         B, N, _ = xyz0.shape
-        ws = self._workspace(B, N)
+        ws = self._workspace(B, N, slot)
         st = stream_ptr()
         cfg = self.cfg
         group_levels = [k for k, npnt in enumerate(cfg["npoints"]) if npnt is not None]
-        # ---- furthest point sampling + gather for every level
         if len(group_levels) <= 3 and N <= 1024:
             m = (ctypes.c_int * 3)(*([cfg["npoints"][k] for k in group_levels] + [0] * (3 - len(group_levels))))
             pi = [ptr(ws["fps_idx"][l]) if l < len(group_levels) else None for l in range(3)]
@@ -75,6 +78,21 @@ class Pointnet2EncoderHIP:
                 _lib.call("gp_furthest_point_sampling", B, cur.shape[1], npnt, ptr(cur), ptr(temp), ptr(ws["fps_idx"][l]), st)
                 torch.gather(cur, 1, ws["fps_idx"][l].long().unsqueeze(-1).expand(B, npnt, 3), out=ws["new_xyz"][l])
                 cur = ws["new_xyz"][l]
+        return xyz0
+
+    def forward(self, pts, return_intermediates=False, slot=0, centres_done=False):
+        _lib.check_device()
+        if not pts.is_cuda or pts.dtype != torch.float32:
+            raise RuntimeError("pts must be a float32 CUDA tensor")
+        xyz0 = pts[..., 0:3].contiguous()
+        B, N, _ = xyz0.shape
+        ws = self._workspace(B, N, slot)
+        st = stream_ptr()
+        cfg = self.cfg
+        group_levels = [k for k, npnt in enumerate(cfg["npoints"]) if npnt is not None]
+        # ---- furthest point sampling + gather for every level
+        if not centres_done:
+            self.sample_centres(pts, slot)
         # ---- set abstraction levels
         xyz, feats, n, cin = xyz0, None, N, 0
         for k, npnt in enumerate(cfg["npoints"]):

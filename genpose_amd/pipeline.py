@@ -17,7 +17,7 @@ class PipelinedPCPredictor:
     score_agent : genpose_amd.posenet_agent.PoseNet (weights loaded, sampler_mode ['pc'])
     """
 
-    def __init__(self, score_agent, B, K, num_steps, depth=2, sampler_streams=1, batches_per_launch=1, overlap=True):
+    def __init__(self, score_agent, B, K, num_steps, depth=2, sampler_streams=1, batches_per_launch=1, overlap=True, fps_ahead=True):
         """batches_per_launch = G > 1: G consecutive batches share every encoder and sampler launch (the batch-global
         coupling of the sampler stays per batch - gp_pc_step_grouped); at B*K = 3200 rows this lets the sampler run on
         32-row tiles (MFMA-bound) instead of 16-row tiles (weight-stream-bound): 21 vs 26 us per batch and step."""
@@ -37,6 +37,13 @@ class PipelinedPCPredictor:
         self.s_smp = [torch.cuda.Stream(self.dev, priority=-1) for _ in range(sampler_streams)] if overlap else [self.s_enc]
         self.smp = [{self.G: PCSampler(self.net.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False, groups=self.G)}
                     for _ in range(sampler_streams)]
+        # furthest point sampling of the NEXT launch group runs on a side stream while the MFMA stages of the current group
+        # own the chip: it is a latency-bound chain of 893 block-wide argmax steps per cloud (one workgroup per cloud, tiny
+        # LDS), 7 % of the encoder when it runs alone, and fits next to the 8-wave sampler workgroups.
+        self.fps_ahead = fps_ahead
+        self.s_fps = torch.cuda.Stream(self.dev, priority=0) if fps_ahead else None
+        self.ev_fps = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_enc_done = [torch.cuda.Event() for _ in range(depth)]  # encoder of a slot finished with its FPS workspace
         self.timing = False
         self.smp_events = []
         R = B * K
@@ -64,7 +71,28 @@ class PipelinedPCPredictor:
         for st in self.s_smp:
             st.wait_stream(cur)
         B1, K, G = self.B1, self.K, self.G
-        for c, i0 in enumerate(range(0, len(batches), G)):
+        starts = list(range(0, len(batches), G))
+        cat = lambda i0: batches[i0] if len(batches[i0:i0 + G]) == 1 else torch.cat(list(batches[i0:i0 + G]), dim=0)
+        enc = self.net.pts_encoder
+        staged = {}  # launch group -> concatenated clouds whose centres are being sampled on the side stream
+
+        def stage_fps(c):
+            if not self.fps_ahead or c >= len(starts):
+                return
+            slot = c % self.depth
+            with torch.cuda.stream(self.s_fps):
+                self.s_fps.wait_stream(cur)
+                self.s_fps.wait_event(self.ev_enc_done[slot])  # the slot's previous centres are no longer read
+                pts = cat(starts[c])
+                pts.record_stream(self.s_enc)  # allocated here, consumed by the encoder stream
+                enc.sample_centres(pts, slot=slot)
+                self.ev_fps[slot].record(self.s_fps)
+            staged[c] = pts
+
+        for e in self.ev_enc_done:
+            e.record(self.s_enc)
+        stage_fps(0)
+        for c, i0 in enumerate(starts):
             group = batches[i0:i0 + G]
             g = len(group)
             nb, nr = g * B1, g * B1 * K
@@ -72,8 +100,16 @@ class PipelinedPCPredictor:
             # ---- encoder stage (stream E): features -> per-cloud embedding, prior -> device
             with torch.cuda.stream(self.s_enc):
                 self.s_enc.wait_event(self.ev_free[slot])  # the sampler has consumed this slot's previous contents
-                pts = group[0] if g == 1 else torch.cat(list(group), dim=0)
-                feat = self.net.pts_encoder(pts)
+                if c in staged:
+                    pts = staged.pop(c)
+                    self.s_enc.wait_event(self.ev_fps[slot])
+                    feat = enc.forward(pts, slot=slot, centres_done=True)
+                else:
+                    pts = cat(i0)
+                    feat = enc.forward(pts, slot=slot)
+                self.ev_enc_done[slot].record(self.s_enc)
+            stage_fps(c + 1)  # queued behind nothing: runs under this group's remaining encoder stages and its sampler
+            with torch.cuda.stream(self.s_enc):
                 cv = self.net.pose_score_net.cloud_embed(feat)
                 self.cvec[slot][:nb].copy_(cv)
                 self.centre[slot][:nb].copy_(pts.mean(dim=1))
@@ -110,6 +146,8 @@ class PipelinedPCPredictor:
         for st in self.s_smp:
             cur.wait_stream(st)
         cur.wait_stream(self.s_enc)
+        if self.s_fps is not None:
+            cur.wait_stream(self.s_fps)
         return results
 
     def sampler_launch_seconds(self):
