@@ -17,7 +17,7 @@ P = c_void_p
 class GpScoreNet(ctypes.Structure):
     """struct gp_scorenet (include/genpose_hip.h)."""
     _fields_ = [(n, c_void_p) for n in ("w_pose0", "b_pose0", "w_pose2", "b_pose2", "w_headx", "w_out", "b_out", "fourier_w",
-                                        "w_t1", "b_t1", "w_headt", "w_headp", "b_head")]
+                                        "w_t1", "b_t1", "w_headt", "w_headp", "b_head", "w_headx_t", "w_pose2_t", "w_pose0_t")]
 
 
 NETP = ctypes.POINTER(GpScoreNet)
@@ -49,6 +49,7 @@ SIGNATURES = {
     "gp_pc_step": [c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
     "gp_roi_to_cloud": [c_int, c_int, c_int, c_int, P, P, P, c_float, c_float, c_float, c_float, P, P, P, P],
     "gp_cloud_sample": [c_int, c_int, c_int, P, P, P, P, P],
+    "gp_score_div": [c_int, c_int, NETP, P, P, P, P, P, P, P, P],
     "gp_pc_tile_rows": [c_int, c_int, c_int],
     "gp_pc_step_grouped": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
     "gp_rk45_state_bytes": [],

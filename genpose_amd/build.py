@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libgenpose_hip.so")
-SOURCES = ["misc.hip", "pn2_ops.hip", "sa_mlp.hip", "scorenet.hip", "rk45.hip", "rank.hip", "preprocess.hip"]
+SOURCES = ["misc.hip", "pn2_ops.hip", "sa_mlp.hip", "scorenet.hip", "rk45.hip", "rank.hip", "preprocess.hip", "score_div.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
 TIMING = bool(os.environ.get("GP_TIMING"))  # tuning build: phase timestamps (needs relocatable device code)
 if TIMING:

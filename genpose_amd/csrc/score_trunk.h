@@ -174,12 +174,17 @@ __device__ __forceinline__ void head_ops_load(HeadOps<PT, NV> &o, const float *l
     }
 }
 
-// f_theta (+ output bias) for the tile's rows -> H1[r*LDH + j], j < 9.
+struct TrunkNoEmit {};
+
+// f_theta (+ output bias) for the tile's rows -> H1[r*LDH + j], j < 9  (KEEP_H1: -> X0[r*LD0 + 12 + j] instead, so that the
+// post-ReLU activations of both hidden layers stay intact in H1 / H2 for a backward pass).
 // Preconditions: x rows in X0 (cols 0..8, zero padded to 16) + ONE __syncthreads(); trunk_begin() issued earlier.
 // rows >= nrows are clamped duplicates.
-template <int P>
+// emit(h, chunk index, p-chunk, post-ReLU head activations f32x4, w_out rows of the head for these 4 channels, channel 0..767):
+// optional hook on every head-layer fragment (the backward seed of gp_score_div is built there).
+template <int P, bool KEEP_H1 = false, class Emit = TrunkNoEmit>
 __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net, const float *__restrict__ cvec, const float *__restrict__ tvec,
-                                             int row0, int nrows, int kcand, TrunkPre<P> &pre) {
+                                             int row0, int nrows, int kcand, TrunkPre<P> &pre, Emit emit = Emit()) {
     using L = TrunkLds<P>;
     constexpr int PT = P / 16, NW = TrunkCfg<P>::NW, NV = TrunkCfg<P>::NV, NT = TrunkCfg<P>::NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,6 +243,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
                 v.y = fmaxf(v.y, 0.f);
                 v.z = fmaxf(v.z, 0.f);
                 v.w = fmaxf(v.w, 0.f);
+                if constexpr (!__is_same(Emit, TrunkNoEmit)) emit(h, i, p, v, o.w0[i], o.w1[i], o.w2[i], nch[h][i] * 16 + 4 * (lane >> 4));
                 part[p][0] += v.x * o.w0[i].x + v.y * o.w0[i].y + v.z * o.w0[i].z + v.w * o.w0[i].w;
                 part[p][1] += v.x * o.w1[i].x + v.y * o.w1[i].y + v.z * o.w1[i].z + v.w * o.w1[i].w;
                 part[p][2] += v.x * o.w2[i].x + v.y * o.w2[i].y + v.z * o.w2[i].z + v.w * o.w2[i].w;
@@ -260,7 +266,10 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < 4 * NW; ++q) v += red[(q * P + r) * 12 + j];
-            H1[r * L::LDH + j] = v + pre.bout[it];  // parked in H1 (free now)
+            if constexpr (KEEP_H1)
+                X0[r * L::LD0 + 12 + j] = v + pre.bout[it];  // x sits in columns 0..8; 12..20 are padding by now
+            else
+                H1[r * L::LDH + j] = v + pre.bout[it];  // parked in H1 (free now)
         }
     }
     __syncthreads();

@@ -47,6 +47,16 @@ class ScoreNetHIP:
         _lib.call("gp_score_eval", B, k, self.w.ref(), ptr(cvec), ptr(tvec), ptr(x), ptr(sigma_dev), m, ptr(out), stream_ptr())
         return out
 
+    def score_and_divergence(self, cvec, k, x, eps, tvec, sigma_dev):
+        """score [B*k,9] and the Hutchinson divergence estimate eps^T (d score / d x) eps [B*k] in one launch (gp_score_div)."""
+        _lib.check_device()
+        B = cvec.shape[0]
+        R = B * k
+        score = torch.empty(R, 9, device=self.device)
+        div = torch.empty(R, device=self.device)
+        _lib.call("gp_score_div", B, k, self.w.ref(), ptr(cvec), ptr(tvec), ptr(x), ptr(eps), ptr(sigma_dev), ptr(score), ptr(div), stream_ptr())
+        return score, div
+
     def forward_rows(self, pts_feat_rows, pose, t, mode="score"):
         """Reference-shaped call: pts_feat [R,1024] (one feature row per pose row), pose [R,9], t [R,1] (uniform)."""
         tt = t.reshape(-1)

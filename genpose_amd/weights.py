@@ -130,6 +130,10 @@ class ScoreNetWeights:
         t["w_headt"] = W1[:, 1024:1152].t().contiguous()  # [128][768]
         t["w_headp"] = pack_weight(W1[:, :1024].contiguous())
         t["b_head"] = b1.contiguous()
+        # transposed packs: backward pass of gp_score_div
+        t["w_headx_t"] = pack_weight(W1[:, 1152:1408].t().contiguous())
+        t["w_pose2_t"] = pack_weight(g("pose_encoder.2.weight").t().contiguous())
+        t["w_pose0_t"] = pack_weight(g("pose_encoder.0.weight").t().contiguous())
         self.tensors = {k: v.to(device) for k, v in t.items()}
         self.struct = _lib.GpScoreNet(**{k: v.data_ptr() for k, v in self.tensors.items()})
 

@@ -150,6 +150,10 @@ typedef struct gp_scorenet {
     const float *w_headt; /* [128 in][768 out]: t_feat columns of the three head first layers, TRANSPOSED */
     const float *w_headp; /* packed [768 x 1024]: pts_feat columns of the three head first layers */
     const float *b_head;  /* [768] */
+    /* transposed packs for the backward pass of gp_score_div (d score / d pose); unused by every other entry point */
+    const float *w_headx_t; /* packed [256 x 768] = w_headx^T */
+    const float *w_pose2_t; /* packed [256 x 256] = pose_encoder.2.weight^T */
+    const float *w_pose0_t; /* packed [9 x 256]   = pose_encoder.0.weight^T */
 } gp_scorenet;
 
 /* cvec[b,768] = W_headp . pts_feat[b] + b_head  (hoisted once per cloud; exact algebra). */
@@ -161,6 +165,13 @@ int gp_time_embed(int nt, const gp_scorenet *net, const float *t, float *tvec, g
  * mode 0: out[R,9] = f_theta/(sigma+1e-7) (score, scorenet.py:217); mode 1: out[R,2] = IP energy (energynet.py:180-185). */
 int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x,
                   const float *sigma_dev, int mode, float *out, gp_stream_t s);
+
+/* Score and the Skilling-Hutchinson divergence estimate of cond_ode_likelihood (samplers.py:49-71) in one launch:
+ *   score[R,9] = f_theta(x)/(sigma+1e-7);  div[R] = eps^T (d score / d x) eps  - the reference gets it from
+ *   torch.autograd.grad(sum(score * eps), x); here the vector-Jacobian product runs through the transposed weight packs
+ *   (ReLU masks from the forward activations kept in LDS).  x, eps [R,9] f32; tvec [768]; sigma = *sigma_dev. */
+int gp_score_div(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x, const float *eps,
+                 const float *sigma_dev, float *score, float *div, gp_stream_t s);
 
 /* Rows per workgroup tile of the score kernels (size of `partials` = nsteps * ceil(R / tile)). */
 int gp_score_tile_rows(int nrows);

@@ -65,3 +65,26 @@ def test_pc_sampler_golden(nets, golden, use_graph):
         torch.cuda.synchronize()
         np.testing.assert_allclose(mean_x.reshape(B, K, 9).cpu().numpy(), g["pred"], rtol=1e-3, atol=1e-3)
         np.testing.assert_allclose(xs.reshape(B, K, n, 9).cpu().numpy(), g["proc"], rtol=1e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("B,K", [(1, 1), (3, 7), (5, 50)])
+def test_score_and_divergence_vs_autograd(nets, B, K):
+    """gp_score_div: score and eps^T (d score / d x) eps of cond_ode_likelihood (samplers.py:49-62) against torch autograd on
+    the oracle's network; ragged tiles, rows of one tile spanning several clouds."""
+    snet, _ = nets
+    sd = go.make_state_dict(0, "score")
+    gen = torch.Generator().manual_seed(21)
+    pf = torch.randn(B, 1024, generator=gen).abs()
+    pose = torch.randn(B * K, 9, generator=gen)
+    eps = torch.randn(B * K, 9, generator=gen) * 3.0
+    for t in (1e-5, 0.2, 0.9):
+        ref_s, ref_d = go.score_and_divergence(sd, pf.repeat_interleave(K, 0), pose, torch.ones(B * K, 1) * t, eps)
+        cvec = snet.cloud_embed(pf.cuda())
+        tvec = snet.time_embed(torch.tensor([t], device="cuda"))
+        sigma = torch.tensor([0.01 * 5000.0 ** t], device="cuda")
+        s, d = snet.score_and_divergence(cvec, K, pose.cuda(), eps.cuda(), tvec[0], sigma)
+        np.testing.assert_allclose(s.cpu().numpy(), ref_s.numpy(), rtol=NET_RTOL, atol=NET_RTOL * float(ref_s.abs().max()))
+        np.testing.assert_allclose(d.cpu().numpy(), ref_d.numpy(), rtol=NET_RTOL, atol=NET_RTOL * float(ref_d.abs().max()))
+        # same score as the plain evaluation
+        s0 = snet.evaluate(cvec, K, pose.cuda(), tvec[0], sigma, "score")
+        np.testing.assert_allclose(s.cpu().numpy(), s0.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(ref_s.abs().max()))
