@@ -99,6 +99,21 @@ class GFObjectPose:
             return smp.run(cvec, centre, x0, T0, num_steps=self.cfg.sampling_steps, eps=self.sampling_eps, return_process=return_process)
         raise NotImplementedError(sampler)
 
+    def calc_likelihood(self, data, atol=1e-5, rtol=1e-5):
+        """posenet.py:133-147: log-likelihood (bits) of data['sampled_pose'] under the score model, one probe per row drawn from
+        the prior.  data['pts_feat'] must be there (mode 'pts_feature')."""
+        from .likelihood import cond_ode_likelihood
+        self._need_weights()
+        if self.cfg.posenet_mode != "score":
+            raise NotImplementedError("likelihoods come from the score model")
+        cvec, K = self._rows(data)
+        x = data["sampled_pose"].float().contiguous()
+        epsilon = self.prior_fn((x.shape[0], 9)).to(self.device)
+        self.last_likelihood_stats = {}
+        _, ll = cond_ode_likelihood(self.pose_score_net, cvec, K, x, epsilon, eps=self.sampling_eps, rtol=rtol, atol=atol,
+                                    stats=self.last_likelihood_stats)
+        return ll
+
     # ------------------------------------------------------------------ string dispatch (posenet.py:150-179)
     def forward(self, data, mode="score", init_x=None, T0=None):
         if mode == "pts_feature":
@@ -115,6 +130,8 @@ class GFObjectPose:
             tvec = self.pose_score_net.time_embed(t0)
             sigma = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t0).contiguous()
             return self.pose_score_net.evaluate(cvec, K, data["sampled_pose"].float().contiguous(), tvec[0], sigma, mode)
+        if mode == "likelihood":
+            return self.calc_likelihood(data)
         if mode == "pc_sample":
             return self.sample(data, "pc", init_x=init_x)
         if mode == "ode_sample":

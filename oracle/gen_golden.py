@@ -344,5 +344,34 @@ def main_g11():
     print("g11_preprocess.npz", os.path.getsize(os.path.join(OUT, "g11_preprocess.npz")))
 
 
+def main_g12():
+    """G12 likelihood: GFObjectPose.forward(mode='likelihood') of the imported reference (posenet.py:133-147, samplers.py:22-99)
+    on 3 clouds, the Hutchinson probe pinned by replacing prior_fn for the call."""
+    from genpose_amd import synth
+    ns = ref_import.load()
+    ag, sd = make_agent(ns, "score")
+    pts = torch.from_numpy(synth.make_batch(3, start=70))
+    data = {"pts": pts.clone(), "pts_center": pts.mean(dim=1)}
+    with torch.no_grad():
+        data["pts_feat"] = ag.net(data, mode="pts_feature")
+    gen = torch.Generator().manual_seed(12)
+    pose = torch.randn(3, 9, generator=gen)
+    pose[:, :6] = go.normalize_rotation(pose[:, :6])
+    pose[:, 6:] = pts.mean(dim=1) + 0.02 * torch.randn(3, 3, generator=gen)
+    probe = torch.randn(3, 9, generator=gen) * 50.0
+    saved = ag.net.prior_fn
+    ag.net.prior_fn = lambda shape, **k: probe.clone()
+    data["sampled_pose"] = pose.clone()
+    ll = ag.net(data, mode="likelihood")
+    ag.net.prior_fn = saved
+    z, ll_o, nfev = go.ode_likelihood(sd, data["pts_feat"], pose, probe)
+    assert np.allclose(ll.numpy(), ll_o.numpy(), rtol=1e-9, atol=1e-9), (ll, ll_o)  # oracle == reference
+    g12 = {"pts": pts.numpy(), "pose": pose.numpy(), "probe": probe.numpy(), "log_likelihood": ll.numpy(), "z": z.numpy(), "nfev": np.array(nfev)}
+    np.savez_compressed(os.path.join(OUT, "g12_likelihood.npz"), **g12)
+    print("g12_likelihood.npz", ll.numpy(), "nfev", nfev)
+
+
 if __name__ == "__main__":
+    if "--g12" in sys.argv:
+        sys.exit(main_g12())
     sys.exit(main_g11() if "--g11" in sys.argv else (main_g10() if "--g10" in sys.argv else main()))

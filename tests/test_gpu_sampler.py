@@ -185,3 +185,26 @@ def test_tracking_golden(golden):
         np.testing.assert_allclose(out["init_x"].cpu().numpy(), g[f"f{fi}_init_x"], atol=2e-4 if fi else 1e-6)
         ode_close(out["pred_pose"].cpu().numpy(), g[f"f{fi}_pred"])
         np.testing.assert_allclose(out["average_sRT"].cpu().numpy(), g[f"f{fi}_avg_sRT"], atol=5e-4)
+
+
+def test_likelihood_golden(golden):
+    """mode='likelihood' (posenet.py:133-147, samplers.py:22-99) against the imported reference (fixture G12)."""
+    g = golden("g12_likelihood.npz")
+    agent = make_agent("score", "ode", None)
+    pts = torch.from_numpy(g["pts"]).cuda()
+    data = {"pts": pts, "pts_center": pts.mean(dim=1)}
+    data["pts_feat"] = agent.net(data, mode="pts_feature")
+    data["sampled_pose"] = torch.from_numpy(g["pose"]).cuda()
+    probe = torch.from_numpy(g["probe"])
+    saved = agent.net.prior_fn
+    agent.net.prior_fn = lambda shape, **k: probe.clone()
+    try:
+        ll = agent.net(data, mode="likelihood")
+    finally:
+        agent.net.prior_fn = saved
+    assert ll.dtype == torch.float64 and ll.shape == (3,)
+    ref = g["log_likelihood"]
+    nfev = agent.net.last_likelihood_stats["nfev"]
+    # the integrand is O(1e4) bits over ~1.8e4 adaptive evaluations of a random-weight network: relative agreement
+    np.testing.assert_allclose(ll.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    assert abs(nfev - int(g["nfev"])) <= 0.05 * int(g["nfev"]), (nfev, int(g["nfev"]))

@@ -154,3 +154,14 @@ def test_rk45_matches_scipy():
         assert nfev == ref.nfev
         np.testing.assert_allclose(ts, ref.t, rtol=0, atol=1e-15)
         np.testing.assert_allclose(ys, ref.y, rtol=1e-13, atol=1e-14)
+
+
+def test_likelihood_oracle_equals_reference(golden):
+    """oracle.ode_likelihood reproduces the imported reference's mode='likelihood' output (fixture G12) - ~20 s of CPU."""
+    g = golden("g12_likelihood.npz")
+    sd = go.make_state_dict(0, "score")
+    feat = go.encoder_forward(sd, torch.from_numpy(g["pts"]))
+    z, ll, nfev = go.ode_likelihood(sd, feat, torch.from_numpy(g["pose"]), torch.from_numpy(g["probe"]))
+    assert nfev == int(g["nfev"])
+    np.testing.assert_allclose(ll.numpy(), g["log_likelihood"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(z.numpy(), g["z"], rtol=1e-9, atol=1e-9)
