@@ -235,7 +235,7 @@ def main():
             "metric": "poses/sec (1024-pt cloud, 50 cand x 100 SDE steps)", "value": round(value, 2), "unit": "poses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {B} clouds/GPU x 1024 pts, {K} candidates, "
+            "config": {"workload": f"configs[{2 if energy_agent is not None else 1}]: {B} clouds/GPU x 1024 pts, {K} candidates, "
                                    + (f"PC sampler {n} steps (NFE={n})" if args.sampler == "pc" else f"ODE sampler RK45 T0={T0} (NFE={nfev})")
                                    + (", ScoreNet only" if energy_agent is None else ", + EnergyNet ranking + top-60% aggregation"),
                        "clouds_per_gpu": B, "candidates": K, "sde_steps": n, "sampler": args.sampler, "pipeline": args.pipeline, "stream_pipelining": bool(pipelined and args.overlap), "batches_per_launch": G,
