@@ -184,3 +184,54 @@ def test_synth_is_deterministic_and_real275_shaped():
     assert np.allclose(a[..., 2] * 1000, np.round(a[..., 2] * 1000), atol=1e-3)  # 1 mm depth quantisation
     g = synth.golden_clouds()
     assert len(np.unique(g[2], axis=0)) < 1024  # tiled duplicates present (FPS ties)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under genpose_amd/ may import it, and bench.py / __graft_entry__.py only
+    inside the CPU-baseline leg and smoke() (as the checker).  Checked on the import statements of every product module and by
+    importing the whole package with `oracle` made unimportable."""
+    import ast
+    import importlib
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    for path in sorted((root / "genpose_amd").glob("*.py")):
+        tree = ast.parse(path.read_text())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{path.name} imports the oracle"
+    # bench.py: the only oracle import sits inside run_cpu_baseline; __graft_entry__.py: inside smoke()/build()
+    for fname, allowed in (("bench.py", {"run_cpu_baseline"}), ("__graft_entry__.py", {"smoke", "build"})):
+        tree = ast.parse((root / fname).read_text())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            for node in ast.walk(fn):
+                mods = [a.name for a in node.names] if isinstance(node, ast.Import) else ([node.module or ""] if isinstance(node, ast.ImportFrom) else [])
+                if any(m == "oracle" or m.startswith("oracle.") for m in mods):
+                    assert fn.name in allowed, f"{fname}:{fn.name} imports the oracle"
+        for node in tree.body:  # module level
+            mods = [a.name for a in node.names] if isinstance(node, ast.Import) else ([node.module or ""] if isinstance(node, ast.ImportFrom) else [])
+            assert not any(m == "oracle" or m.startswith("oracle.") for m in mods), f"{fname} imports the oracle at module level"
+
+    class _Block:
+        def find_spec(self, name, path=None, target=None):
+            if name == "oracle" or name.startswith("oracle."):
+                raise ImportError("the oracle is not available to the product")
+            return None
+
+    saved = {k: v for k, v in sys.modules.items() if k == "oracle" or k.startswith("oracle.") or k == "genpose_amd" or k.startswith("genpose_amd.")}
+    for k in saved:
+        del sys.modules[k]
+    sys.meta_path.insert(0, _Block())
+    try:
+        for path in sorted((root / "genpose_amd").glob("*.py")):
+            if path.stem not in ("__init__", "build"):
+                importlib.import_module(f"genpose_amd.{path.stem}")
+    finally:
+        sys.meta_path.pop(0)
+        for k in [k for k in sys.modules if k == "genpose_amd" or k.startswith("genpose_amd.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
