@@ -119,9 +119,21 @@ def main():
     if pipelined:
         from genpose_amd.pipeline import PipelinedPCPredictor
         pipe = PipelinedPCPredictor(score_agent, B, K, n, batches_per_launch=args.batches_per_launch, overlap=args.overlap)
-    G = args.batches_per_launch if pipelined else 1
+    ode_grouped = args.sampler == "ode" and args.pipeline == "score" and not args.no_pipeline and args.batches_per_launch > 1
+    ode_pred = None
+    if ode_grouped:
+        from genpose_amd.pipeline import GroupedODEPredictor
+        ode_pred = GroupedODEPredictor(score_agent, B, K, T0=T0, batches_per_launch=args.batches_per_launch)
+    G = args.batches_per_launch if (pipelined or ode_grouped) else 1
 
     def run_steps(count):
+        if ode_grouped:
+            outs = ode_pred.run([pts] * count)
+            if dist is not None:
+                for o in outs:
+                    gathered = [torch.empty_like(o) for _ in range(world)]
+                    dist.all_gather(gathered, o.contiguous())
+            return
         if not pipelined:
             for _ in range(count):
                 step()
@@ -133,7 +145,7 @@ def main():
                 dist.all_gather(gathered, o)
 
     step()  # builds samplers / captures graphs outside the timed region
-    if pipelined:
+    if pipelined or ode_grouped:
         for g in sorted({G, args.warmup % G, args.steps % G} - {0}, reverse=True):
             run_steps(g)  # captures the G-batch graph and the graph of the ragged tail this run will meet
     run_steps(args.warmup)
@@ -195,8 +207,11 @@ def main():
             roofline["in_situ_avg_launch_us"] = round(in_situ * 1e6, 2)
             roofline["in_situ_achieved"] = round(flops_per_launch / in_situ / 1e12, 2)
     else:
-        st = score_agent.net._samplers[("ode", B, K)].last_stats
-        nfev = int(st["nfev"])
+        if ode_grouped:
+            nfev = int(round(sum(ode_pred.last_nfev) / max(1, len(ode_pred.last_nfev))))
+        else:
+            st = score_agent.net._samplers[("ode", B, K)].last_stats
+            nfev = int(st["nfev"])
 
     # the same workload with ONE batch per launch (no request batching), reported next to the headline for comparison
     one_batch = None

@@ -66,7 +66,8 @@ __device__ __forceinline__ void set_stage(Rk45State *st, int slot, double t) {
 
 struct OdeArgs {
     int nrows, kcand, nblocks;
-    const float *cvec, *tvec;  // tvec [8][768] (slot-indexed like stage_t)
+    int ngroups, bpg, rows_per_group;  // independent batches laid out back to back: one solver state (step control) per group
+    const float *cvec, *tvec;  // tvec [ngroups][8][768] (slot-indexed like stage_t)
     const float *centre;
     Rk45State *st;
     double *y, *ynew, *K;      // y, ynew [R*9]; K [7][R*9]
@@ -96,12 +97,14 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double sh[8];
     const int row0 = blockIdx.x * P, tid = threadIdx.x;
-    Rk45State *st = a.st;
+    const int grp = blockIdx.x / a.bpg;
+    Rk45State *st = a.st + grp;
     if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
     const size_t n = (size_t)a.nrows * 9;
     const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
+    const float *tvec = a.tvec + ((size_t)grp * 8 + slot) * HEADS;
     TrunkPre<P> pre;
-    trunk_begin<P>(net, pre, a.cvec, a.tvec + (size_t)slot * HEADS, row0, a.nrows, a.kcand);
+    trunk_begin<P>(net, pre, a.cvec, tvec, row0, a.nrows, a.kcand);
     const double h = st->h;
     const float sigma = st->stage_sigma[slot];  // requested now, used after the trunk
     const double g2 = st->stage_g2[slot];
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
         for (int j = 9; j < 16; ++j) xr[j] = 0.f;
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, a.tvec + (size_t)slot * HEADS, row0, a.nrows, a.kcand, pre);
+    trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, a.nrows, a.kcand, pre);
     const float *F = lds + L::OFF_H1;
     double *Kout = a.K + (size_t)(STAGE == 7 ? 1 : (STAGE == 0 ? 0 : (STAGE == 6 ? 6 : STAGE))) * n;
     double acc0 = 0.0, acc1 = 0.0;
@@ -218,11 +221,12 @@ __device__ void begin_attempt(Rk45State *st) {
 // mode 2: after an attempt (error norm -> accept / reject -> next attempt)
 __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
     __shared__ double sh[8];
-    Rk45State *st = a.st;
-    const double nn = (double)a.nrows * 9.0;
+    Rk45State *st = a.st + blockIdx.x;  // one workgroup per group
+    const double *part = a.partials + (size_t)blockIdx.x * a.bpg;
+    const double nn = (double)a.rows_per_group * 9.0;
     if (mode == 0) {
-        const double s0 = sum_partials(a.partials, a.nblocks, sh);
-        const double s1 = sum_partials(a.partials + a.nblocks, a.nblocks, sh);
+        const double s0 = sum_partials(part, a.bpg, sh);
+        const double s1 = sum_partials(part + a.nblocks, a.bpg, sh);
         if (threadIdx.x == 0) {
             const double d0 = sqrt(s0) / sqrt(nn), d1 = sqrt(s1) / sqrt(nn);  // norm(x) = |x|_2 / sqrt(size)
             const double interval = fabs(st->t_bound - st->t);
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
             st->nfev = 1;
         }
     } else if (mode == 1) {
-        const double s0 = sum_partials(a.partials, a.nblocks, sh);
+        const double s0 = sum_partials(part, a.bpg, sh);
         if (threadIdx.x == 0) {
             const double d2 = (sqrt(s0) / sqrt(nn)) / st->h0;
             const double d1 = st->d1;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
         }
     } else {
         if (st->status != 0) return;
-        const double s0 = sum_partials(a.partials, a.nblocks, sh);
+        const double s0 = sum_partials(part, a.bpg, sh);
         if (threadIdx.x == 0) {
             const double err = sqrt(s0) / sqrt(nn);
             const int ia = st->n_attempts;
@@ -296,16 +300,17 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
 
 // Record the accepted state (raw) into the trajectory; runs after decide (multi-block, elementwise).
 __global__ void rk45_record_kernel(OdeArgs a) {
-    const Rk45State *st = a.st;
-    if (!a.traj || !st->last_accepted) return;
+    const Rk45State *st = a.st + blockIdx.y;  // grid (64, ngroups): every group records its own rows at its own slot
+    if (!a.traj || !st->last_accepted || st->status < 0) return;
     const size_t n = (size_t)a.nrows * 9;
+    const size_t e_lo = (size_t)blockIdx.y * a.rows_per_group * 9, e_hi = e_lo + (size_t)a.rows_per_group * 9;
     if (st->n_eval > 0) {
         // 4th-order dense output of the step just accepted (rk.py RkDenseOutput): y(t) = y_old + h * Q . [x, x^2, x^3, x^4],
         // Q = K^T P, x = (t - t_old) / h.  y is still y_old here (the commit happens in the next attempt's first stage).
         const int mb = st->emit_begin, me = st->emit_end;
         if (mb >= me) return;
         const double h = st->h_acc, t_old = st->t_old;
-        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        for (size_t e = e_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_hi; e += (size_t)gridDim.x * blockDim.x) {
             double Q[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int sgi = 0; sgi < 7; ++sgi) {
@@ -324,7 +329,7 @@ __global__ void rk45_record_kernel(OdeArgs a) {
     }
     const int slot = st->n_accepted;  // slot 0 holds y0
     if (slot >= st->traj_cap) return;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+    for (size_t e = e_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_hi; e += (size_t)gridDim.x * blockDim.x)
         a.traj[(size_t)slot * n + e] = a.ynew[e];
 }
 
@@ -334,10 +339,12 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
     using L = TrunkLds<P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int row0 = blockIdx.x * P, tid = threadIdx.x;
-    const Rk45State *st = a.st;
+    const int grp = blockIdx.x / a.bpg;
+    const Rk45State *st = a.st + grp;
     const double *yfin = st->last_accepted ? a.ynew : a.y;
+    const float *tvec = a.tvec + (size_t)grp * 8 * HEADS;  // slot 0 = eps
     TrunkPre<P> pre;
-    trunk_begin<P>(net, pre, a.cvec, a.tvec, row0, a.nrows, a.kcand);
+    trunk_begin<P>(net, pre, a.cvec, tvec, row0, a.nrows, a.kcand);
     if (tid < P) {
         const int r = row0 + tid < a.nrows ? row0 + tid : a.nrows - 1;
         float *xr = lds + tid * L::LD0;
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
         for (int j = 9; j < 16; ++j) xr[j] = 0.f;
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, a.tvec, row0, a.nrows, a.kcand, pre);  // slot 0 = eps
+    trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, a.nrows, a.kcand, pre);
     const float sigma = st->stage_sigma[0];
     const float *F = lds + L::OFF_H1;
     if (tid < P && row0 + tid < a.nrows) {
@@ -390,7 +397,8 @@ __global__ void rk45_traj_post_kernel(int nrows, int kcand, int nstates, const f
 }
 
 __global__ void rk45_reset_kernel(Rk45State *st, double t0, double t_bound, double rtol, double atol, int traj_cap, double eps_time) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    st += blockIdx.x;  // one block per group
     st->t = t0, st->t_bound = t_bound, st->direction = t_bound >= t0 ? 1.0 : -1.0;
     st->rtol = rtol, st->atol = atol;
     st->h = 0, st->h_abs = 0, st->d0 = st->d1 = st->h0 = 0, st->err_norm = 0;
@@ -408,14 +416,15 @@ struct DenseP {
     double p[7][4];
 };
 __global__ void rk45_set_dense_kernel(Rk45State *st, const double *t_eval, int n_eval, DenseP P) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    st += blockIdx.x;
     st->t_eval = t_eval, st->n_eval = n_eval, st->next_eval = 0, st->emit_begin = st->emit_end = 0;
     for (int i = 0; i < 7; ++i)
         for (int c = 0; c < 4; ++c) st->Pm[i][c] = P.p[i][c];
 }
 
 __global__ void rk45_set_slot0_kernel(Rk45State *st, double t) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) set_stage(st, 0, t);
+    if (threadIdx.x == 0) set_stage(st + blockIdx.x, 0, t);
 }
 
 template <typename K>
@@ -445,16 +454,16 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
     const size_t n = (size_t)a.nrows * 9;
     switch (phase) {
         case 0:
-            hipLaunchKernelGGL(rk45_reset_kernel, dim3(1), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
+            hipLaunchKernelGGL(rk45_reset_kernel, dim3(a.ngroups), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
             if (traj && hipMemcpyAsync(traj, y, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return GP_ELAUNCH;
             break;
         case 1:
             hipLaunchKernelGGL((rk45_stage_kernel<P, 0>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk1, 0, st, a, 0);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 0);
             break;
         case 2:
             hipLaunchKernelGGL((rk45_stage_kernel<P, 7>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk1, 0, st, a, 1);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
             break;
         case 3:
             hipLaunchKernelGGL((rk45_stage_kernel<P, 1>), grid, blk, lds, st, a, *net);
@@ -463,11 +472,11 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             hipLaunchKernelGGL((rk45_stage_kernel<P, 4>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL((rk45_stage_kernel<P, 5>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL((rk45_stage_kernel<P, 6>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), blk1, 0, st, a, 2);
-            if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64), blk1, 0, st, a);
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
+            if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64, a.ngroups), blk1, 0, st, a);
             break;
         case 4:
-            hipLaunchKernelGGL(rk45_set_slot0_kernel, dim3(1), dim3(64), 0, st, a.st, t0);
+            hipLaunchKernelGGL(rk45_set_slot0_kernel, dim3(a.ngroups), dim3(64), 0, st, a.st, t0);
             break;
         case 5:
             if (!x_out) return GP_EINVAL;
@@ -488,13 +497,17 @@ int64_t gp_rk45_state_bytes(void) { return (int64_t)sizeof(Rk45State); }
 /* Dense-output mode (solve_ivp(..., t_eval=...)): call after phase 0.  t_eval: device array [n_eval] f64 (monotone in the
  * integration direction, as np.linspace(T0, eps, n)); P: the 7x4 dense-output matrix of RK45 in HOST memory (row-major;
  * scipy.integrate RK45.P).  traj must then hold [n_eval][R*9]: slot m receives the interpolated state at t_eval[m]. */
-int gp_rk45_set_dense(void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s) {
-    if (!state || !t_eval_dev || n_eval <= 0 || !P_host) return GP_EINVAL;
+int gp_rk45_set_dense_grouped(int ngroups, void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s) {
+    if (ngroups <= 0 || !state || !t_eval_dev || n_eval <= 0 || !P_host) return GP_EINVAL;
     DenseP P;
     for (int i = 0; i < 7; ++i)
         for (int c = 0; c < 4; ++c) P.p[i][c] = P_host[i * 4 + c];
-    hipLaunchKernelGGL(rk45_set_dense_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (Rk45State *)state, t_eval_dev, n_eval, P);
+    hipLaunchKernelGGL(rk45_set_dense_kernel, dim3(ngroups), dim3(64), 0, (hipStream_t)s, (Rk45State *)state, t_eval_dev, n_eval, P);
     return gp_launch_status();
+}
+
+int gp_rk45_set_dense(void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s) {
+    return gp_rk45_set_dense_grouped(1, state, t_eval_dev, n_eval, P_host, s);
 }
 
 /* Field offsets for host-side inspection: fills out[0..15] with byte offsets of
@@ -517,35 +530,53 @@ int gp_rk45_state_layout(int64_t *out, int n) {
     return GP_OK;
 }
 
-static int ode_args(OdeArgs *a, int nclouds, int k, const float *cvec, const float *tvec, const float *centre, void *state, double *y,
-                    double *ynew, double *K, double *partials, double *traj, float *x32) {
-    if (nclouds <= 0 || k <= 0 || !cvec || !tvec || !centre || !state || !y || !ynew || !K || !partials) return GP_EINVAL;
-    a->nrows = nclouds * k, a->kcand = k;
-    { const int P = score_tile_rows(a->nrows); a->nblocks = (a->nrows + P - 1) / P; }
+static int ode_args(OdeArgs *a, int *tile, int ngroups, int nclouds_per_group, int k, const float *cvec, const float *tvec, const float *centre,
+                    void *state, double *y, double *ynew, double *K, double *partials, double *traj, float *x32) {
+    if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || !cvec || !tvec || !centre || !state || !y || !ynew || !K || !partials) return GP_EINVAL;
+    const int rg = nclouds_per_group * k;
+    int P = score_tile_rows(ngroups * rg);
+    if (ngroups > 1 && rg % P != 0) P = 16;  // tiles must not straddle groups
+    if (ngroups > 1 && rg % P != 0) return GP_EINVAL;
+    a->nrows = ngroups * rg, a->kcand = k;
+    a->ngroups = ngroups, a->rows_per_group = rg, a->bpg = (rg + P - 1) / P, a->nblocks = a->bpg * ngroups;
     a->cvec = cvec, a->tvec = tvec, a->centre = centre, a->st = (Rk45State *)state;
     a->y = y, a->ynew = ynew, a->K = K, a->partials = partials, a->traj = traj, a->x32 = x32;
+    *tile = P;
     return GP_OK;
 }
 
 /* Phase driver.  Every phase is a fixed launch sequence on stream s (graph-capturable):
  *   phase 0: reset state (t0 -> t_bound), y must hold y0; copies y0 into traj slot 0 when traj != NULL
- *   phase 1: f0 + d0/d1 -> h0          [needs tvec slot 0 = time_embed(stage_t[0]) BEFORE it: see gp_rk45_stage_times]
+ *   phase 1: f0 + d0/d1 -> h0          [needs tvec slot 0 = time_embed(stage_t[0]) BEFORE it]
  *   phase 2: f1 + d2 -> h_abs, first attempt's stage times
  *   phase 3: one attempt: 6 stage kernels + decide + record
  *   phase 4: set slot 0 to `eps_t` (denoise evaluation time)
  *   phase 5: finish: denoise + normalise + centre -> x_out [R,9] f64; post-process nstates trajectory states
- * Between phases the caller runs gp_time_embed(8, net, stage_times_dev, tvec) where stage_times_dev points at
- * Rk45State.stage_t (offset from gp_rk45_state_layout). */
+ * Between phases the caller runs gp_time_embed_strided(8, ngroups, gp_rk45_state_bytes()/4, net, stage_times_dev, tvec) where
+ * stage_times_dev points at group 0's Rk45State.stage_t (offset from gp_rk45_state_layout).
+ * ngroups independent batches (nclouds_per_group clouds each, rows / clouds / state laid out group-major) advance with their OWN
+ * step controllers - error norm, accept / reject, step size per group, exactly as separate solve_ivp calls - and share every
+ * launch; a finished group's workgroups exit at once.  state: ngroups * gp_rk45_state_bytes(); tvec [ngroups][8][768];
+ * partials [3][nblocks], nblocks = ngroups * ceil(rows_per_group / tile), tile from gp_pc_tile_rows. */
+int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, const float *tvec,
+                          const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
+                          double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
+                          gp_stream_t s) {
+    OdeArgs a;
+    int P = 0;
+    int rc = ode_args(&a, &P, ngroups, nclouds_per_group, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
+    if (rc != GP_OK || !net) return GP_EINVAL;
+    return P == 16 ? rk45_phase_impl<16>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                         (hipStream_t)s)
+                   : rk45_phase_impl<32>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                         (hipStream_t)s);
+}
+
 int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state,
                   double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap, double t0, double t_bound, double rtol,
                   double atol, double denoise_scale, int do_denoise, int nstates, double *x_out, gp_stream_t s) {
-    OdeArgs a;
-    int rc = ode_args(&a, nclouds, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
-    if (rc != GP_OK || !net) return GP_EINVAL;
-    return score_tile_rows(a.nrows) == 16 ? rk45_phase_impl<16>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise,
-                                                                nstates, centre, x_out, (hipStream_t)s)
-                                         : rk45_phase_impl<32>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise,
-                                                                nstates, centre, x_out, (hipStream_t)s);
+    return gp_rk45_phase_grouped(phase, 1, nclouds, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap, t0, t_bound, rtol, atol,
+                                 denoise_scale, do_denoise, nstates, x_out, s);
 }
 
 }  // extern "C"

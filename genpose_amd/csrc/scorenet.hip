@@ -45,10 +45,12 @@ __global__ __launch_bounds__(256) void cloud_embed_kernel(int nb, gp_scorenet ne
 // ---------------------------------------------------------------------------------------------- time embed
 // tvec[i, 768] = W1t . relu(Wt1 . [sin(x), cos(x)] + bt1),  x = t * W * 2 * pi   (scorenet.py:55-64,111-116)
 // w_t1 and w_headt arrive TRANSPOSED ([k][n]) so consecutive threads read consecutive words.
-__global__ __launch_bounds__(256) void time_embed_kernel(gp_scorenet net, const float *__restrict__ t, float *__restrict__ tvec) {
+// grid (nt, ngroups): group g reads its nt time values at t + g * t_stride and writes tvec rows [g*nt, (g+1)*nt)
+__global__ __launch_bounds__(256) void time_embed_kernel(gp_scorenet net, const float *__restrict__ t, size_t t_stride, float *__restrict__ tvec) {
     __shared__ float four[128], tf[128];
     const int tid = threadIdx.x;
-    const float tv = t[blockIdx.x];
+    const float tv = t[(size_t)blockIdx.y * t_stride + blockIdx.x];
+    tvec += (size_t)blockIdx.y * gridDim.x * HEADS;
     if (tid < 64) {
         const float xp = ((tv * net.fourier_w[tid]) * 2.0f) * 3.14159274101257324f;  // f32 evaluation order of the reference
         four[tid] = sinf(xp);
@@ -271,7 +273,14 @@ int gp_cloud_embed(int b, const gp_scorenet *net, const float *pts_feat, float *
 int gp_time_embed(int nt, const gp_scorenet *net, const float *t, float *tvec, gp_stream_t s) {
     if (nt < 0 || !net || !t || !tvec) return GP_EINVAL;
     if (nt == 0) return GP_OK;
-    hipLaunchKernelGGL(time_embed_kernel, dim3(nt), dim3(256), 0, (hipStream_t)s, *net, t, tvec);
+    hipLaunchKernelGGL(time_embed_kernel, dim3(nt), dim3(256), 0, (hipStream_t)s, *net, t, (size_t)0, tvec);
+    return gp_launch_status();
+}
+
+int gp_time_embed_strided(int nt, int ngroups, int64_t t_stride_floats, const gp_scorenet *net, const float *t, float *tvec, gp_stream_t s) {
+    if (nt < 0 || ngroups < 0 || t_stride_floats < 0 || !net || !t || !tvec) return GP_EINVAL;
+    if (nt == 0 || ngroups == 0) return GP_OK;
+    hipLaunchKernelGGL(time_embed_kernel, dim3(nt, ngroups), dim3(256), 0, (hipStream_t)s, *net, t, (size_t)t_stride_floats, tvec);
     return gp_launch_status();
 }
 

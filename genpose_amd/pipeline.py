@@ -8,7 +8,7 @@ import torch
 
 from . import _lib
 from .samplers import PCSampler
-from .sde import SIGMA_MAX
+from .sde import SIGMA_MAX, SIGMA_MIN
 
 
 class PipelinedPCPredictor:
@@ -157,3 +157,59 @@ class PipelinedPCPredictor:
             return None
         tot = sum(a.elapsed_time(b) for a, b, _ in self.smp_events) * 1e-3
         return tot / (len(self.smp_events) * (self.n + 1))
+
+
+class GroupedODEPredictor:
+    """pred_func(encoder + PF-ODE sampler) for a stream of equally-shaped batches, `batches_per_launch` of them sharing every encoder
+    pass and every launch of the device-resident RK45 driver.  Each batch keeps its own adaptive step control
+    (gp_rk45_phase_grouped), i.e. gets what `PoseNet.pred_func` returns for it alone; the host only polls the per-batch status
+    words between replays of the captured attempts."""
+
+    def __init__(self, score_agent, B, K, T0=None, batches_per_launch=5):
+        from .samplers import ODESampler
+        _lib.check_device()
+        self.net = score_agent.net
+        self.net._need_weights()
+        self.B1, self.K, self.G = B, K, batches_per_launch
+        self.T0 = self.net.T if T0 is None else T0
+        self.dev = self.net.device
+        self._ODESampler = ODESampler
+        self.smp = {}
+        self.last_nfev = []
+
+    def _sampler(self, g):
+        if g not in self.smp:
+            self.smp[g] = self._ODESampler(self.net.pose_score_net, self.B1 * g, self.K, self.dev, groups=g)
+        return self.smp[g]
+
+    def run(self, batches, prior_noise=None):
+        """batches: sequence of device tensors [B,1024,3] -> list of pred_pose [B,K,9] float64 (one per batch)."""
+        self.last_nfev = []
+        B1, K, G = self.B1, self.K, self.G
+        n = len(batches)
+        out = torch.empty(n, B1, K, 9, dtype=torch.float64, device=self.dev)  # one allocation per call, filled group by group
+        if not hasattr(self, "_pts"):
+            N = batches[0].shape[1]
+            self._pts = torch.empty(G * B1, N, 3, device=self.dev)
+            self._x0 = torch.empty(G * B1 * K, 9, device=self.dev)
+            self._prior_host = torch.empty(G * B1 * K, 9).pin_memory()
+        for i0 in range(0, n, G):
+            g = min(G, n - i0)
+            pts = self._pts[: g * B1]
+            for q in range(g):
+                pts[q * B1:(q + 1) * B1].copy_(batches[i0 + q])
+            cvec = self.net.pose_score_net.cloud_embed(self.net.pts_encoder(pts))
+            x0 = self._x0[: g * B1 * K]
+            if prior_noise is None:
+                host = self._prior_host[: g * B1 * K]
+                torch.randn(host.shape, out=host)  # CPU generator, as sde.py:28
+                x0.copy_(host, non_blocking=True)
+                x0.mul_(SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** self.T0)  # prior std at T0
+            else:
+                for q in range(g):
+                    x0[q * B1 * K:(q + 1) * B1 * K].copy_(prior_noise[i0 + q].reshape(B1 * K, 9))
+            smp = self._sampler(g)
+            _, x = smp.run(cvec, pts.mean(dim=1), x0, self.T0, num_steps=self.net.cfg.sampling_steps, eps=self.net.sampling_eps)
+            self.last_nfev += [int(s["nfev"]) for s in smp.group_stats]
+            out[i0:i0 + g].copy_(x.reshape(g, B1, K, 9))
+        return [out[i] for i in range(n)]

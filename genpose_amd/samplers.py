@@ -115,19 +115,27 @@ class ODESampler:
 
     TRAJ_CAP = 192
 
-    def __init__(self, net, B, K, device, use_graph=True, poll=8):
-        self.net, self.B, self.K = net, B, K
+    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1):
+        """B clouds in `groups` independent batches of B/groups clouds laid out back to back: every batch keeps its own adaptive
+        step control (error norm over ITS rows, accept / reject, step size - what separate cond_ode_sampler calls would do) while
+        all of them share each launch (gp_rk45_phase_grouped)."""
+        if B % groups:
+            raise ValueError(f"{B} clouds do not split into {groups} equal batches")
+        self.net, self.B, self.K, self.groups = net, B, K, groups
         self.dev = torch.device(device)
         R = self.R = B * K
-        self.tile = _lib.lib().gp_score_tile_rows(R)
-        self.nblocks = (R + self.tile - 1) // self.tile
+        self.tile = _lib.lib().gp_pc_tile_rows(groups, B // groups, K)
+        if self.tile < 0:
+            raise ValueError(f"{B // groups} clouds x {K} candidates per batch is not a multiple of the 16-row tile; run the batches separately")
+        self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
         self.layout, nbytes = _state_layout()
-        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)
+        self.state_bytes = nbytes
+        self.state = torch.zeros(groups * nbytes, dtype=torch.uint8, device=self.dev)
         d = lambda *s: torch.zeros(*s, dtype=torch.float64, device=self.dev)
         self.y, self.ynew, self.Kbuf = d(R * 9), d(R * 9), d(7, R * 9)
         self.partials = d(3, self.nblocks)
         self.x_out = d(R, 9)
-        self.tvec = torch.zeros(8, 768, device=self.dev)
+        self.tvec = torch.zeros(groups * 8, 768, device=self.dev)
         self.cvec = torch.empty(B, 768, device=self.dev)
         self.centre = torch.empty(B, 3, device=self.dev)
         self.traj = None
@@ -140,7 +148,7 @@ class ODESampler:
     def _phase(self, phase, traj=None, t0=0.0, t_bound=0.0, rtol=1e-5, atol=1e-5, dscale=0.0, do_denoise=1, nstates=0):
         import ctypes
         cd = ctypes.c_double
-        _lib.call("gp_rk45_phase", phase, self.B, self.K, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec), ptr(self.centre),
+        _lib.call("gp_rk45_phase_grouped", phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec), ptr(self.centre),
                   ptr(self.state), ptr(self.y), ptr(self.ynew), ptr(self.Kbuf), ptr(self.partials), ptr(traj),
                   0 if traj is None else traj.shape[0], cd(t0), cd(t_bound), cd(rtol), cd(atol), cd(dscale), do_denoise, nstates,
                   ptr(self.x_out), stream_ptr())
@@ -148,14 +156,20 @@ class ODESampler:
     def _embed(self):
         import ctypes
         stage_t = ctypes.c_void_p(self.state.data_ptr() + self.layout["stage_t"])
-        _lib.call("gp_time_embed", 8, self.net.w.ref(), stage_t, ptr(self.tvec), stream_ptr())
+        _lib.call("gp_time_embed_strided", 8, self.groups, self.state_bytes // 4, self.net.w.ref(), stage_t, ptr(self.tvec), stream_ptr())
 
     def _attempt(self, traj):
         self._embed()
         self._phase(3, traj)
 
-    def _read_state(self):
-        raw = self.state.cpu().numpy()
+    def _read_states(self):
+        raw_all = self.state.cpu().numpy()  # one D2H copy for all groups
+        return [self._parse_state(raw_all[g * self.state_bytes:(g + 1) * self.state_bytes]) for g in range(self.groups)]
+
+    def _read_state(self, group=0):
+        return self._read_states()[group]
+
+    def _parse_state(self, raw):
         L = self.layout
         g = lambda name, dt, n=1: np.frombuffer(raw.tobytes(), dtype=dt, count=n, offset=L[name])
         st = {k: g(k, np.int32)[0] for k in ("status", "n_attempts", "n_accepted", "nfev")}
@@ -170,6 +184,8 @@ class ODESampler:
         """Returns (xs [R,S,9] f64 or None, x [R,9] f64).  With num_steps=None the in-process samples are the accepted
         states (like solve_ivp without t_eval)."""
         dense = return_process and num_steps is not None
+        if self.groups > 1 and return_process and not dense:
+            raise NotImplementedError("accepted-state trajectories have a different length per batch: ask for them one batch at a time")
         self.cvec.copy_(cvec)
         self.centre.copy_(centre)
         self.y.copy_(init_x.reshape(-1).double())  # init_x f32 -> f64 state (solve_ivp casts y0 to float64)
@@ -187,7 +203,8 @@ class ODESampler:
             traj = self._dense_traj
             self._phase(0, None, t0=T0, t_bound=eps, rtol=rtol, atol=atol)
             Pm = np.ascontiguousarray(RK45.P, dtype=np.float64)
-            _lib.call("gp_rk45_set_dense", ptr(self.state), ptr(self._t_eval), num_steps, Pm.ctypes.data_as(ctypes.c_void_p), stream_ptr())
+            _lib.call("gp_rk45_set_dense_grouped", self.groups, ptr(self.state), ptr(self._t_eval), num_steps, Pm.ctypes.data_as(ctypes.c_void_p),
+                      stream_ptr())
         else:
             if return_process:
                 if self.traj is None:
@@ -215,13 +232,15 @@ class ODESampler:
                 for _ in range(self.poll):
                     self._attempt(traj)
             n_done += self.poll
-            st = self._read_state()
-            if st["status"] != 0:
+            sts = self._read_states()
+            if all(s_["status"] != 0 for s_ in sts):
                 break
             if n_done >= max_attempts:
                 raise RuntimeError("ODE sampler: attempt budget exhausted")
-        if st["status"] < 0:
+        if any(s_["status"] < 0 for s_ in sts):
             raise RuntimeError("ODE sampler: required step size is less than spacing between numbers (scipy TOO_SMALL_STEP)")
+        st = sts[0]
+        self.group_stats = sts
         self._phase(4, traj, t0=eps)
         self._embed()
         nstates = (num_steps if dense else int(st["n_accepted"]) + 1) if traj is not None else 0
@@ -229,7 +248,8 @@ class ODESampler:
             raise RuntimeError(f"ODE sampler: {nstates} accepted states exceed the trajectory capacity {self.TRAJ_CAP}")
         dscale = (1 - eps) / (1000 if num_steps is None else num_steps)
         self._phase(5, traj, dscale=dscale, do_denoise=1 if denoise else 0, nstates=nstates)
-        st["nfev"] = int(st["nfev"]) + (1 if denoise else 0)
+        for s_ in sts:
+            s_["nfev"] = int(s_["nfev"]) + (1 if denoise else 0)
         self.last_stats = st
         xs = None
         if traj is not None:

@@ -160,6 +160,9 @@ typedef struct gp_scorenet {
 int gp_cloud_embed(int b, const gp_scorenet *net, const float *pts_feat, float *cvec, gp_stream_t s);
 /* tvec[nt,768] = W_headt . relu(W_t1 . fourier(t) + b_t1) for nt time values read from DEVICE memory (f32). */
 int gp_time_embed(int nt, const gp_scorenet *net, const float *t, float *tvec, gp_stream_t s);
+/* ngroups sets of nt time values, set g at t + g * t_stride_floats -> tvec[(g*nt + i), 768] (the grouped RK45 driver reads its stage
+ * times straight out of the per-group solver states). */
+int gp_time_embed_strided(int nt, int ngroups, int64_t t_stride_floats, const gp_scorenet *net, const float *t, float *tvec, gp_stream_t s);
 
 /* f_theta / score / energy for R = nclouds*k rows.  x [R,9] f32; tvec [768]; sigma = *sigma_dev (f32).
  * mode 0: out[R,9] = f_theta/(sigma+1e-7) (score, scorenet.py:217); mode 1: out[R,2] = IP energy (energynet.py:180-185). */
@@ -225,6 +228,18 @@ int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const f
                   void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap, double t0,
                   double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                   gp_stream_t s);
+
+/* The same driver over `ngroups` independent batches that share every launch while keeping their OWN step controllers (error norm,
+ * accept / reject and step size per group, exactly as separate solve_ivp calls); a finished group's workgroups exit at once.
+ * Rows, clouds and solver states are laid out group-major: state = ngroups * gp_rk45_state_bytes(), tvec [ngroups][8][768]
+ * (gp_time_embed_strided(8, ngroups, gp_rk45_state_bytes() / 4, net, &state[0].stage_t, tvec)), partials [3][nblocks] with
+ * nblocks = ngroups * ceil(rows_per_group / tile), tile = gp_pc_tile_rows(ngroups, nclouds_per_group, k) (rows of a group must be
+ * a multiple of it).  traj: every group writes its own rows at its own accepted-step slot. */
+int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, const float *tvec,
+                          const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
+                          double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
+                          gp_stream_t s);
+int gp_rk45_set_dense_grouped(int ngroups, void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * D. Ranking and aggregation (reward.py:131-155, sgpa_utils.py:897-954, evaluation_tracking.py:60-77)

@@ -116,3 +116,30 @@ def test_runner_evaluate_end_to_end(tmp_path):
                                                                    use_matches_for_pose=True, repeat_num=K, ratio=0.6)
     for c in (1, 3, 6):  # classes present
         assert pose_aps[c, 0, 0] == 1.0 and iou_aps[c, 0] > 0.0, (c, pose_aps[c], iou_aps[c])
+
+
+def test_grouped_ode_predictor_equals_agent():
+    """GroupedODEPredictor (several batches per launch, per-batch step control) returns for every batch what the agent's
+    pred_func returns for it alone."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.pipeline import GroupedODEPredictor
+    from genpose_amd.posenet_agent import PoseNet
+    B, K, NB, T0 = 4, 8, 3, 0.3
+    agent = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"]))
+    agent.load_state_dict(go.make_state_dict(0, "score"))
+    gen = torch.Generator().manual_seed(4)
+    batches = [torch.from_numpy(synth.make_batch(B, start=11 * i)).cuda() for i in range(NB)]
+    sig = float(go.ve_sigma(torch.tensor(T0)))
+    priors = [torch.randn(B * K, 9, generator=gen) * sig * (1 + i) for i in range(NB)]
+    seq = []
+    for i in range(NB):
+        agent.net.prior_fn = lambda shape, T=1.0, i=i: priors[i]
+        seq.append(agent.pred_func({"pts": batches[i], "pts_center": batches[i].mean(dim=1)}, K, save_path=None, T0=T0).clone())
+    pred = GroupedODEPredictor(agent, B, K, T0=T0, batches_per_launch=2)
+    got = pred.run(batches, prior_noise=priors)
+    torch.cuda.synchronize()
+    assert len(got) == NB and len(pred.last_nfev) == NB
+    for i in range(NB):
+        scale = max(1.0, float(seq[i].abs().max()))
+        np.testing.assert_allclose(got[i].cpu().numpy(), seq[i].cpu().numpy(), rtol=0, atol=5e-4 * scale, err_msg=f"batch {i}")

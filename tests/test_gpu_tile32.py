@@ -87,3 +87,39 @@ def test_ode_sampler_32_row_tiles(nets):
     assert int(smp.last_stats["nfev"]) == nfev
     scale = max(1.0, float(ref.abs().max()))
     np.testing.assert_allclose(x.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-4 * scale)
+
+
+@pytest.mark.parametrize("G,B1,K", [(2, 4, 8), (3, 2, 16), (2, 64, 50)])
+def test_grouped_ode_sampler_keeps_per_batch_step_control(nets, G, B1, K):
+    """G batches share every launch of the RK45 driver (gp_rk45_phase_grouped) but each keeps its own controller: every batch's
+    accept / reject sequence, evaluation count and result are what it gets when solved alone (the last case runs on 32-row
+    tiles, the stand-alone solves on 16-row tiles: same schedule, results within the ODE tolerance)."""
+    from genpose_amd.samplers import ODESampler
+    snet, _ = nets
+    T0 = 0.3
+    gen = torch.Generator().manual_seed(100 + G)
+    pf = torch.randn(G * B1, 1024, generator=gen).abs()
+    centre = torch.randn(G * B1, 3, generator=gen) * 0.3
+    R1 = B1 * K
+    init_x = torch.randn(G * R1, 9, generator=gen) * float(go.ve_sigma(torch.tensor(T0)))
+    for g in range(G):
+        init_x[g * R1:(g + 1) * R1] *= 1.0 + 0.7 * g  # different scales -> different step sequences per batch
+    cvec = snet.cloud_embed(pf.cuda())
+    grouped = ODESampler(snet, G * B1, K, "cuda", groups=G)
+    _, xg = grouped.run(cvec, centre.cuda(), init_x.cuda(), T0)
+    torch.cuda.synchronize()
+    alone = ODESampler(snet, B1, K, "cuda")
+    accs = []
+    for g in range(G):
+        rows, cl = slice(g * R1, (g + 1) * R1), slice(g * B1, (g + 1) * B1)
+        _, xa = alone.run(cvec[cl], centre[cl].cuda(), init_x[rows].cuda(), T0)
+        torch.cuda.synchronize()
+        sa, sg = alone.last_stats, grouped.group_stats[g]
+        accs.append(tuple(int(v) for v in sa["log_acc"]))
+        assert int(sg["status"]) == 1 and int(sg["nfev"]) == int(sa["nfev"]), (g, sg["nfev"], sa["nfev"])
+        assert [int(v) for v in sg["log_acc"]] == [int(v) for v in sa["log_acc"]]
+        np.testing.assert_allclose(sg["log_t"], sa["log_t"], rtol=1e-4, atol=1e-9)  # tile size changes the summation order of the error norm
+        np.testing.assert_allclose(sg["log_err"], sa["log_err"], rtol=2e-2, atol=1e-4)
+        scale = max(1.0, float(xa.abs().max()))
+        np.testing.assert_allclose(xg[rows].cpu().numpy(), xa.cpu().numpy(), rtol=0, atol=5e-4 * scale)
+    assert len(set(accs)) > 1 or G == 1  # the batches really took different step sequences
