@@ -63,11 +63,19 @@ __global__ __launch_bounds__(256) void time_embed_kernel(gp_scorenet net, const 
         tf[tid] = fmaxf(acc + net.b_t1[tid], 0.f);
     }
     __syncthreads();
-    for (int n = tid; n < HEADS; n += 256) {
-        float acc = 0.f;
-        for (int k = 0; k < 128; ++k) acc = fmaf(tf[k], net.w_headt[k * HEADS + n], acc);
-        tvec[(size_t)blockIdx.x * HEADS + n] = acc;
+    // three outputs per thread, their k-ordered fmaf chains interleaved (same arithmetic per output, 3x the ILP)
+    static_assert(HEADS == 3 * 256, "one pass of three outputs per thread");
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const float *w = net.w_headt + tid;
+#pragma unroll 4
+    for (int k = 0; k < 128; ++k) {
+        const float tk = tf[k];
+        a0 = fmaf(tk, w[k * HEADS], a0);
+        a1 = fmaf(tk, w[k * HEADS + 256], a1);
+        a2 = fmaf(tk, w[k * HEADS + 512], a2);
     }
+    float *o = tvec + (size_t)blockIdx.x * HEADS + tid;
+    o[0] = a0, o[256] = a1, o[512] = a2;
 }
 
 // mode 0: score = f/(sigma+1e-7)  (scorenet.py:217);  mode 1: IP energy with s = f/sigma (energynet.py:163-185)
