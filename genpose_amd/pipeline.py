@@ -11,6 +11,17 @@ from .samplers import PCSampler
 from .sde import SIGMA_MAX, SIGMA_MIN
 
 
+def _randn_1t(out):
+    """Standard-normal draw on the CPU generator into `out`, single-threaded: a multi-threaded CPU op leaves its OpenMP team
+    spinning next to the HIP runtime's progress thread (see GFObjectPose._prior_to_device)."""
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        torch.randn(out.shape, out=out)
+    finally:
+        torch.set_num_threads(nt)
+
+
 class PipelinedPCPredictor:
     """pred_func(encoder + PC sampler) for a stream of equally-shaped batches.
 
@@ -117,7 +128,7 @@ class PipelinedPCPredictor:
                 if prior_noise is None:
                     self.ev_h2d[slot].synchronize()  # host may run `depth` launches ahead, not further (pinned buffer reuse)
                     host = self.prior_host[slot][:nr]
-                    torch.randn(host.shape, out=host)  # CPU generator, as sde.py:28
+                    _randn_1t(host)  # CPU generator, as sde.py:28
                     x0.copy_(host, non_blocking=True)
                     self.ev_h2d[slot].record(self.s_enc)
                 else:
@@ -202,7 +213,7 @@ class GroupedODEPredictor:
             x0 = self._x0[: g * B1 * K]
             if prior_noise is None:
                 host = self._prior_host[: g * B1 * K]
-                torch.randn(host.shape, out=host)  # CPU generator, as sde.py:28
+                _randn_1t(host)  # CPU generator, as sde.py:28
                 x0.copy_(host, non_blocking=True)
                 x0.mul_(SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** self.T0)  # prior std at T0
             else:

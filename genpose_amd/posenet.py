@@ -70,6 +70,37 @@ class GFObjectPose:
         cvec = self.pose_score_net.cloud_embed(data["pts_feat"].float())
         return cvec, K
 
+    def _prior_to_device(self, shape, **kw):
+        """prior_fn draws on the CPU generator like the reference (sde.py:28); the result goes through a cached PINNED staging
+        buffer - a pageable host-to-device copy takes the runtime's slow path (staging allocation, occasional multi-ms stalls)."""
+        # single-threaded on purpose: a multi-threaded CPU op leaves its OpenMP team spinning next to the HIP runtime's
+        # progress thread, and every few calls a sampler graph replay stalls for 60-70 ms (measured at 256 clouds:
+        # 12.9 ms per pred_func with one thread, 13 / 13 / 73 ms with the default 128)
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            return self._prior_to_device_1t(shape, **kw)
+        finally:
+            torch.set_num_threads(nt)
+
+    def _prior_to_device_1t(self, shape, **kw):
+        cpu = self.prior_fn(shape, **kw)
+        if cpu.is_cuda:
+            return cpu.float()
+        key = tuple(cpu.shape)
+        st = self._staging.get(key) if hasattr(self, "_staging") else None
+        if st is None:
+            if not hasattr(self, "_staging"):
+                self._staging = {}
+            st = self._staging[key] = (torch.empty(key, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+            st[1].record()
+        pinned, ev = st
+        ev.synchronize()  # the previous copy out of the pinned buffer has completed
+        pinned.copy_(cpu)
+        dev = pinned.to(self.device, non_blocking=True)
+        ev.record()
+        return dev
+
     def sample(self, data, sampler, init_x=None, T0=None, noise=None, return_process=True):
         self._need_weights()
         cvec, K = self._rows(data)
@@ -80,7 +111,7 @@ class GFObjectPose:
             n = self.cfg.sampling_steps
             if n is None:
                 raise ValueError("the PC sampler needs cfg.sampling_steps")
-            x0 = self.prior_fn((R, 9)).to(self.device) if init_x is None else init_x.float()
+            x0 = self._prior_to_device((R, 9)) if init_x is None else init_x.float()
             key = ("pc", B, K, n, return_process)
             smp = self._samplers.get(key)
             if smp is None:
@@ -90,7 +121,7 @@ class GFObjectPose:
             return (xs.clone() if xs is not None else None), res.clone()
         if sampler == "ode":
             T0 = self.T if T0 is None else T0
-            pr = self.prior_fn((R, 9), T=T0).to(self.device)
+            pr = self._prior_to_device((R, 9), T=T0)
             x0 = pr if init_x is None else init_x.float() + pr
             key = ("ode", B, K)
             smp = self._samplers.get(key)
