@@ -11,6 +11,10 @@ python scratch/prof_summary.py $O/prof_seq/run_results.db > $O/kernel_summary.tx
 timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --overlap > $O/bench_line_overlap.json 2>/dev/null
 timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --batches-per-launch 1 --overlap > $O/bench_line_g1_overlap.json 2>/dev/null
 timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --batches-per-launch 1 > $O/bench_line_g1.json 2>/dev/null
+timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --sampler ode > $O/bench_line_ode.json 2>/dev/null
+timeout 200 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --sampler ode --batches-per-launch 1 > $O/bench_line_ode_g1.json 2>/dev/null
+timeout 300 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --pipeline full --batch 256 > $O/bench_line_full256.json 2>/dev/null
+timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --pipeline full --batch 256 --sampler ode > $O/bench_line_full256_ode.json 2>/dev/null
 for B in 64 320; do
   timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$B -o run -- python scratch/microbench.py $B 50 > $O/pmc_fetch_$B.log 2>&1
   timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$B -o run -- python scratch/microbench.py $B 50 > $O/pmc_write_$B.log 2>&1
