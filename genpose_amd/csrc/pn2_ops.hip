@@ -219,21 +219,27 @@ struct FpsChainArgs {
     float *new_xyz[3];
 };
 
+// LDS (dynamic): coordinate planes A [3][n0] and B [3][m0] that the levels ping-pong between (every level is at most as large as
+// the one before, so level l+1 always fits the buffer level l-1 lived in) + the selected indices [m0]: 20.3 KB for 1024 -> 512 ->
+// 256 -> 128 - small enough to share a CU with a 135 KB score-network workgroup of another stream.
 __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
-    __shared__ float cur[2][3][1024];
-    __shared__ int32_t sel[1024];
+    extern __shared__ float fps_lds[];
     __shared__ unsigned long long slots[2][FPS_T / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int cap[2] = {a.n0, a.m[0]};
+    float *plane[2] = {fps_lds, fps_lds + 3 * a.n0};
+    int32_t *sel = reinterpret_cast<int32_t *>(fps_lds + 3 * a.n0 + 3 * a.m[0]);
     const float *xyz = a.xyz + (size_t)b * a.n0 * 3;
     for (int i = tid; i < a.n0 * 3; i += FPS_T) {
         int k = i / 3, c = i - k * 3;
-        cur[0][c][k] = xyz[i];
+        plane[0][c * cap[0] + k] = xyz[i];
     }
     __syncthreads();
     int n = a.n0, buf = 0;
     for (int l = 0; l < a.nlevels; ++l) {
         const int m = a.m[l];
-        float *sx = cur[buf][0], *sy = cur[buf][1], *sz = cur[buf][2];
+        float *sx = plane[buf], *sy = plane[buf] + cap[buf], *sz = plane[buf] + 2 * cap[buf];
+        float *nx = plane[buf ^ 1], *ny = plane[buf ^ 1] + cap[buf ^ 1], *nz = plane[buf ^ 1] + 2 * cap[buf ^ 1];
         if (n == 4 * FPS_T)
             fps_pass<4, true>(n, m, sx, sy, sz, nullptr, sel, slots);
         else if (n == 2 * FPS_T)
@@ -256,9 +262,9 @@ __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
             gx[j * 3 + 0] = x;
             gx[j * 3 + 1] = y;
             gx[j * 3 + 2] = z;
-            cur[buf ^ 1][0][j] = x;
-            cur[buf ^ 1][1][j] = y;
-            cur[buf ^ 1][2][j] = z;
+            nx[j] = x;
+            ny[j] = y;
+            nz[j] = z;
         }
         __syncthreads();
         n = m;
@@ -510,7 +516,8 @@ int gp_fps_chain(int b, int n0, int nlevels, const int *m, const float *xyz, int
             prev = m[l];
         }
     }
-    hipLaunchKernelGGL(fps_chain_kernel, dim3(b), dim3(FPS_T), 0, (hipStream_t)s, a);
+    const size_t lds = ((size_t)3 * n0 + 4 * (size_t)a.m[0]) * sizeof(float);
+    hipLaunchKernelGGL(fps_chain_kernel, dim3(b), dim3(FPS_T), lds, (hipStream_t)s, a);
     return gp_launch_status();
 }
 
