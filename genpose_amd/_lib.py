@@ -58,6 +58,8 @@ SIGNATURES = {
     "gp_rk45_phase": [c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
     "gp_rk45_phase_grouped": [c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
     "gp_rk45_set_dense_grouped": [c_int, P, P, c_int, P, P],
+    "gp_rk45_phase_ragged": [c_int, c_int, P, c_int, P, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5
+                            + [c_int, c_int, P, P],
     "gp_time_embed_strided": [c_int, c_int, c_int64, NETP, P, P, P],
     "gp_rank_aggregate": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
 }

@@ -67,6 +67,9 @@ __device__ __forceinline__ void set_stage(Rk45State *st, int slot, double t) {
 struct OdeArgs {
     int nrows, kcand, nblocks;
     int ngroups, bpg, rows_per_group;  // independent batches laid out back to back: one solver state (step control) per group
+    // ragged groups (different numbers of clouds per group; null = equal groups): per workgroup {group, first row, end row},
+    // per group {first workgroup, workgroups, rows, first row}
+    const int *blk_info, *grp_info;
     const float *cvec, *tvec;  // tvec [ngroups][8][768] (slot-indexed like stage_t)
     const float *centre;
     Rk45State *st;
@@ -75,6 +78,17 @@ struct OdeArgs {
     double *traj;              // [traj_cap][R*9] accepted states (raw, un-normalised) or null
     float *x32;                // [R*9] scratch
 };
+
+// which group / rows does this workgroup serve
+template <int P>
+__device__ __forceinline__ void ode_block(const OdeArgs &a, int &grp, int &row0, int &row_end) {
+    if (a.blk_info) {
+        const int *bi = a.blk_info + 3 * blockIdx.x;
+        grp = bi[0], row0 = bi[1], row_end = bi[2];
+    } else {
+        grp = blockIdx.x / a.bpg, row0 = blockIdx.x * P, row_end = a.nrows;
+    }
+}
 
 __device__ __forceinline__ double block_sum(double v, double *sh) {
     const int tid = threadIdx.x;
@@ -96,21 +110,22 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
     using L = TrunkLds<P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double sh[8];
-    const int row0 = blockIdx.x * P, tid = threadIdx.x;
-    const int grp = blockIdx.x / a.bpg;
+    const int tid = threadIdx.x;
+    int grp, row0, rend;
+    ode_block<P>(a, grp, row0, rend);
     Rk45State *st = a.st + grp;
     if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
     const size_t n = (size_t)a.nrows * 9;
     const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
     const float *tvec = a.tvec + ((size_t)grp * 8 + slot) * HEADS;
     TrunkPre<P> pre;
-    trunk_begin<P>(net, pre, a.cvec, tvec, row0, a.nrows, a.kcand);
+    trunk_begin<P>(net, pre, a.cvec, tvec, row0, rend, a.kcand);
     const double h = st->h;
     const float sigma = st->stage_sigma[slot];  // requested now, used after the trunk
     const double g2 = st->stage_g2[slot];
     if (tid < P) {
-        const bool live = row0 + tid < a.nrows;
-        const int r = live ? row0 + tid : a.nrows - 1;
+        const bool live = row0 + tid < rend;
+        const int r = live ? row0 + tid : rend - 1;
         double ys[9];
         if (STAGE == 1 && st->last_accepted) {
             // commit the previous accepted step for this tile's rows (row-local: no other block touches them)
@@ -149,13 +164,13 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
         for (int j = 9; j < 16; ++j) xr[j] = 0.f;
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, a.nrows, a.kcand, pre);
+    trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre);
     const float *F = lds + L::OFF_H1;
     double *Kout = a.K + (size_t)(STAGE == 7 ? 1 : (STAGE == 0 ? 0 : (STAGE == 6 ? 6 : STAGE))) * n;
     double acc0 = 0.0, acc1 = 0.0;
     for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
         const int r = e / POSE, j = e - r * POSE;
-        if (row0 + r >= a.nrows) continue;
+        if (row0 + r >= rend) continue;
         const size_t ge = (size_t)(row0 + r) * 9 + j;
         const float score = F[r * L::LDH + j] / (sigma + 1e-7f);
         const double kv = 0.0 - (0.5 * g2) * (double)score;  // drift - 0.5 * g^2 * score (samplers.py:198)
@@ -222,11 +237,14 @@ __device__ void begin_attempt(Rk45State *st) {
 __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
     __shared__ double sh[8];
     Rk45State *st = a.st + blockIdx.x;  // one workgroup per group
-    const double *part = a.partials + (size_t)blockIdx.x * a.bpg;
-    const double nn = (double)a.rows_per_group * 9.0;
+    const int blk0 = a.grp_info ? a.grp_info[4 * blockIdx.x] : blockIdx.x * a.bpg;
+    const int nblk = a.grp_info ? a.grp_info[4 * blockIdx.x + 1] : a.bpg;
+    const int grows = a.grp_info ? a.grp_info[4 * blockIdx.x + 2] : a.rows_per_group;
+    const double *part = a.partials + blk0;
+    const double nn = (double)grows * 9.0;
     if (mode == 0) {
-        const double s0 = sum_partials(part, a.bpg, sh);
-        const double s1 = sum_partials(part + a.nblocks, a.bpg, sh);
+        const double s0 = sum_partials(part, nblk, sh);
+        const double s1 = sum_partials(part + a.nblocks, nblk, sh);
         if (threadIdx.x == 0) {
             const double d0 = sqrt(s0) / sqrt(nn), d1 = sqrt(s1) / sqrt(nn);  // norm(x) = |x|_2 / sqrt(size)
             const double interval = fabs(st->t_bound - st->t);
@@ -237,7 +255,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
             st->nfev = 1;
         }
     } else if (mode == 1) {
-        const double s0 = sum_partials(part, a.bpg, sh);
+        const double s0 = sum_partials(part, nblk, sh);
         if (threadIdx.x == 0) {
             const double d2 = (sqrt(s0) / sqrt(nn)) / st->h0;
             const double d1 = st->d1;
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
         }
     } else {
         if (st->status != 0) return;
-        const double s0 = sum_partials(part, a.bpg, sh);
+        const double s0 = sum_partials(part, nblk, sh);
         if (threadIdx.x == 0) {
             const double err = sqrt(s0) / sqrt(nn);
             const int ia = st->n_attempts;
@@ -303,7 +321,9 @@ __global__ void rk45_record_kernel(OdeArgs a) {
     const Rk45State *st = a.st + blockIdx.y;  // grid (64, ngroups): every group records its own rows at its own slot
     if (!a.traj || !st->last_accepted || st->status < 0) return;
     const size_t n = (size_t)a.nrows * 9;
-    const size_t e_lo = (size_t)blockIdx.y * a.rows_per_group * 9, e_hi = e_lo + (size_t)a.rows_per_group * 9;
+    const size_t g_row0 = a.grp_info ? a.grp_info[4 * blockIdx.y + 3] : (size_t)blockIdx.y * a.rows_per_group;
+    const size_t g_rows = a.grp_info ? a.grp_info[4 * blockIdx.y + 2] : a.rows_per_group;
+    const size_t e_lo = g_row0 * 9, e_hi = e_lo + g_rows * 9;
     if (st->n_eval > 0) {
         // 4th-order dense output of the step just accepted (rk.py RkDenseOutput): y(t) = y_old + h * Q . [x, x^2, x^3, x^4],
         // Q = K^T P, x = (t - t_old) / h.  y is still y_old here (the commit happens in the next attempt's first stage).
@@ -338,15 +358,16 @@ template <int P>
 __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a, gp_scorenet net, double denoise_scale, int do_denoise, double *x_out) {
     using L = TrunkLds<P>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int row0 = blockIdx.x * P, tid = threadIdx.x;
-    const int grp = blockIdx.x / a.bpg;
+    const int tid = threadIdx.x;
+    int grp, row0, rend;
+    ode_block<P>(a, grp, row0, rend);
     const Rk45State *st = a.st + grp;
     const double *yfin = st->last_accepted ? a.ynew : a.y;
     const float *tvec = a.tvec + (size_t)grp * 8 * HEADS;  // slot 0 = eps
     TrunkPre<P> pre;
-    trunk_begin<P>(net, pre, a.cvec, tvec, row0, a.nrows, a.kcand);
+    trunk_begin<P>(net, pre, a.cvec, tvec, row0, rend, a.kcand);
     if (tid < P) {
-        const int r = row0 + tid < a.nrows ? row0 + tid : a.nrows - 1;
+        const int r = row0 + tid < rend ? row0 + tid : rend - 1;
         float *xr = lds + tid * L::LD0;
 #pragma unroll
         for (int j = 0; j < 9; ++j) xr[j] = (float)yfin[(size_t)r * 9 + j];  // x.float() (:214)
@@ -354,10 +375,10 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
         for (int j = 9; j < 16; ++j) xr[j] = 0.f;
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, a.nrows, a.kcand, pre);
+    trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre);
     const float sigma = st->stage_sigma[0];
     const float *F = lds + L::OFF_H1;
-    if (tid < P && row0 + tid < a.nrows) {
+    if (tid < P && row0 + tid < rend) {
         const int r = row0 + tid;
         double xv[9];
         // vec_eps is an f32 [R,1] tensor: g = sigma * sqrt(2 ln 5000) evaluated in f32 (sde.py:20-24)
@@ -539,6 +560,7 @@ static int ode_args(OdeArgs *a, int *tile, int ngroups, int nclouds_per_group, i
     if (ngroups > 1 && rg % P != 0) return GP_EINVAL;
     a->nrows = ngroups * rg, a->kcand = k;
     a->ngroups = ngroups, a->rows_per_group = rg, a->bpg = (rg + P - 1) / P, a->nblocks = a->bpg * ngroups;
+    a->blk_info = nullptr, a->grp_info = nullptr;
     a->cvec = cvec, a->tvec = tvec, a->centre = centre, a->st = (Rk45State *)state;
     a->y = y, a->ynew = ynew, a->K = K, a->partials = partials, a->traj = traj, a->x32 = x32;
     *tile = P;
@@ -570,6 +592,25 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
                                          (hipStream_t)s)
                    : rk45_phase_impl<32>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
                                          (hipStream_t)s);
+}
+
+int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nblocks, const int32_t *blk_info, int tile, int nclouds_total, int k,
+                         const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state, double *y, double *ynew,
+                         double *K, double *partials, double *traj, int traj_cap, double t0, double t_bound, double rtol, double atol,
+                         double denoise_scale, int do_denoise, int nstates, double *x_out, gp_stream_t s) {
+    if (ngroups <= 0 || nblocks <= 0 || !grp_info || !blk_info || (tile != 16 && tile != 32) || nclouds_total <= 0 || k <= 0 || !net || !cvec ||
+        !tvec || !centre || !state || !y || !ynew || !K || !partials)
+        return GP_EINVAL;
+    OdeArgs a;
+    a.nrows = nclouds_total * k, a.kcand = k, a.nblocks = nblocks;
+    a.ngroups = ngroups, a.bpg = 1, a.rows_per_group = 0;
+    a.blk_info = blk_info, a.grp_info = grp_info;
+    a.cvec = cvec, a.tvec = tvec, a.centre = centre, a.st = (Rk45State *)state;
+    a.y = y, a.ynew = ynew, a.K = K, a.partials = partials, a.traj = traj, a.x32 = nullptr;
+    return tile == 16 ? rk45_phase_impl<16>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                            (hipStream_t)s)
+                      : rk45_phase_impl<32>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                            (hipStream_t)s);
 }
 
 int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state,

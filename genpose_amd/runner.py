@@ -22,6 +22,18 @@ def make_batch_sample(pts):
     return {"pts": pts, "zero_mean_pts": pts - centre.unsqueeze(1), "pts_center": centre}
 
 
+class _one_cpu_thread:
+    """Host-side torch ops inside the per-frame loops run single-threaded: a multi-threaded CPU op leaves its OpenMP team spinning
+    next to the HIP runtime's progress thread and the following graph replays stall for tens of milliseconds."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.n)
+
+
 class SingleFrameRunner:
     """inference_pose + inference_energy (evaluation_single.py:356-489) without the pickle round trip in between."""
 
@@ -125,7 +137,8 @@ class TrackingRunner:
         """pts [n,1024,3] device tensor; gt_RT [n,4,4] (used only for objects not seen in the previous frame)."""
         sample = make_batch_sample(pts)
         dev = sample["pts"].device
-        init_sRT = add_noise_to_RT(gt_RT.float().cpu(), draws=noise_draws).to(dev)  # drawn every frame (:302)
+        with _one_cpu_thread():
+            init_sRT = add_noise_to_RT(gt_RT.float().cpu(), draws=noise_draws).to(dev)  # drawn every frame (:302)
         for i, name in enumerate(model_names):
             if name in self.buffer["model_name"]:
                 init_sRT[i] = self.buffer["pred_sRT"][self.buffer["model_name"].index(name)]
@@ -139,3 +152,88 @@ class TrackingRunner:
         self.buffer = {"model_name": list(model_names), "pred_sRT": average_sRT}
         return {"init_x": init_x, "pred_pose": pred, "energy": energy, "sorted_RTs": rotation.pose9_to_RT(r["sorted_poses"]),
                 "average_sRT": average_sRT}
+
+
+class MultiSequenceTracker:
+    """Tracking (main_tracking, evaluation_tracking.py:262-337) for SEVERAL sequences at once - BASELINE configs[4]: a frame of one
+    sequence is a tiny batch (4-6 objects x 50 candidates), so the frames that different sequences are at share every launch:
+    one encoder pass over all their clouds, one device-resident RK45 solve in which every sequence's frame is a group with
+    its own step control (gp_rk45_phase_ragged - exactly what a per-sequence cond_ode_sampler call does), one energy pass, one
+    ranking launch.  Per sequence the semantics are TrackingRunner's: warm start from the previous frame's aggregated pose
+    of the same `model_name`, else the jittered ground truth; T0 = 0.15."""
+
+    def __init__(self, score_agent, energy_agent, n_sequences, repeat_num=50, T0=0.15, ratio=0.6):
+        self.score_agent, self.energy_agent = score_agent, energy_agent
+        self.repeat_num, self.T0, self.ratio = repeat_num, T0, ratio
+        self.buffers = [{"model_name": [], "pred_sRT": None} for _ in range(n_sequences)]
+        self._samplers = {}
+
+    def reset(self, seq=None):
+        for i in (range(len(self.buffers)) if seq is None else [seq]):
+            self.buffers[i] = {"model_name": [], "pred_sRT": None}
+
+    def step(self, frames, noise_draws=None, prior_noise=None):
+        """frames: one (pts [n_i,1024,3] device, model_names [n_i], gt_RT [n_i,4,4]) per sequence (None = the sequence has no
+        frame this step).  Returns one TrackingRunner-style dict per sequence (None where there was no frame)."""
+        from .samplers import ODESampler
+        net = self.score_agent.net
+        net._need_weights()
+        K = self.repeat_num
+        live = [i for i, f in enumerate(frames) if f is not None and f[0].shape[0] > 0]
+        out = [None] * len(frames)
+        if not live:
+            return out
+        dev = frames[live[0]][0].device
+        counts = [int(frames[i][0].shape[0]) for i in live]
+        pts = torch.cat([frames[i][0].float() for i in live], dim=0)
+        centre = pts.mean(dim=1)
+        # initial poses: jittered ground truth for every object (drawn every frame, evaluation_tracking.py:302) in ONE host call and
+        # one upload, then the warm starts gathered from the previous frames' aggregated poses in one indexed copy
+        gt_all = torch.cat([frames[i][2].float().cpu() for i in live], dim=0)
+        draws_all = None if noise_draws is None else [torch.cat([noise_draws[i][d] for i in live], dim=0) for d in range(4)]
+        with _one_cpu_thread():
+            init_sRT = add_noise_to_RT(gt_all, draws=draws_all).to(dev)
+        prev, src, dst, off, row = [], [], [], 0, 0
+        for q, i in enumerate(live):
+            buf = self.buffers[i]
+            if buf["pred_sRT"] is not None:
+                for j, name in enumerate(frames[i][1]):
+                    if name in buf["model_name"]:
+                        src.append(off + buf["model_name"].index(name))
+                        dst.append(row + j)
+                prev.append(buf["pred_sRT"])
+                off += buf["pred_sRT"].shape[0]
+            row += counts[q]
+        if src:
+            init_sRT[torch.as_tensor(dst, device=dev)] = torch.cat(prev, dim=0)[torch.as_tensor(src, device=dev)].to(init_sRT.dtype)
+        init_x = init_sRT[:, :3, [0, 1, 3]].permute(0, 2, 1).reshape(B0 := init_sRT.shape[0], -1).clone()
+        init_x[:, -3:] -= centre
+        # ---- score model: encoder -> warm-started ODE, one group per sequence
+        feat = net.pts_encoder(pts)
+        cvec = net.pose_score_net.cloud_embed(feat)
+        B = pts.shape[0]
+        if prior_noise is None:
+            pr = net._prior_to_device((B * K, 9), T=self.T0)
+        else:
+            pr = torch.cat([prior_noise[i].reshape(-1, 9) for i in live], dim=0).to(dev).float()
+        x0 = init_x.unsqueeze(1).repeat(1, K, 1).reshape(B * K, 9).float() + pr
+        key = tuple(counts)
+        smp = self._samplers.get(key)
+        if smp is None:
+            smp = self._samplers[key] = ODESampler(net.pose_score_net, B, K, dev, group_clouds=counts)
+        _, x = smp.run(cvec, centre, x0, self.T0, num_steps=net.cfg.sampling_steps, eps=net.sampling_eps)
+        pred = x.reshape(B, K, 9)
+        # ---- energy model + ranking + aggregation for all clouds at once (row / cloud local)
+        energy = self.energy_agent.get_energy(data={"pts": pts, "pts_center": centre}, pose_samples=pred, T=1e-5)
+        sel = max(1, int(self.ratio * K))
+        r = reward.rank_aggregate(pred, energy, selected_num=sel)
+        average_sRT = rotation.quat_trans_to_RT(r["avg_pose"])
+        sorted_RTs = rotation.pose9_to_RT(r["sorted_poses"])
+        lo = 0
+        for q, i in enumerate(live):
+            sl = slice(lo, lo + counts[q])
+            lo += counts[q]
+            self.buffers[i] = {"model_name": list(frames[i][1]), "pred_sRT": average_sRT[sl].clone()}
+            out[i] = {"init_x": init_x[sl], "pred_pose": pred[sl], "energy": energy[sl], "sorted_RTs": sorted_RTs[sl], "average_sRT": average_sRT[sl],
+                      "nfev": int(smp.group_stats[q]["nfev"])}
+        return out

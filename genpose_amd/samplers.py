@@ -115,19 +115,40 @@ class ODESampler:
 
     TRAJ_CAP = 192
 
-    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1):
+    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: every batch keeps its own adaptive
         step control (error norm over ITS rows, accept / reject, step size - what separate cond_ode_sampler calls would do) while
         all of them share each launch (gp_rk45_phase_grouped)."""
-        if B % groups:
+        self.ragged = group_clouds is not None
+        self.dev = torch.device(device)
+        if self.ragged:
+            # groups of different sizes (tracking: the objects of one frame): consecutive cloud ranges, 16-row tiles that end at
+            # the group boundary (gp_rk45_phase_ragged)
+            group_clouds = [int(c) for c in group_clouds]
+            if sum(group_clouds) != B or min(group_clouds) <= 0:
+                raise ValueError(f"group sizes {group_clouds} do not add up to {B} clouds")
+            groups = len(group_clouds)
+            self.tile = _lib.lib().gp_score_tile_rows(B * K)  # 16 rows, or 32 once the launch is big enough to be MFMA-bound
+            blk, grp, row = [], [], 0
+            for g, c in enumerate(group_clouds):
+                rows = c * K
+                nb = (rows + self.tile - 1) // self.tile
+                grp.append([len(blk), nb, rows, row])
+                blk += [[g, row + i * self.tile, row + rows] for i in range(nb)]
+                row += rows
+            self.nblocks = len(blk)
+            self.blk_info = torch.tensor(blk, dtype=torch.int32, device=self.dev)
+            self.grp_info = torch.tensor(grp, dtype=torch.int32, device=self.dev)
+            self.group_clouds = group_clouds
+        elif B % groups:
             raise ValueError(f"{B} clouds do not split into {groups} equal batches")
         self.net, self.B, self.K, self.groups = net, B, K, groups
-        self.dev = torch.device(device)
         R = self.R = B * K
-        self.tile = _lib.lib().gp_pc_tile_rows(groups, B // groups, K)
-        if self.tile < 0:
-            raise ValueError(f"{B // groups} clouds x {K} candidates per batch is not a multiple of the 16-row tile; run the batches separately")
-        self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
+        if not self.ragged:
+            self.tile = _lib.lib().gp_pc_tile_rows(groups, B // groups, K)
+            if self.tile < 0:
+                raise ValueError(f"{B // groups} clouds x {K} candidates per batch is not a multiple of the 16-row tile; run the batches separately")
+            self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
         self.layout, nbytes = _state_layout()
         self.state_bytes = nbytes
         self.state = torch.zeros(groups * nbytes, dtype=torch.uint8, device=self.dev)
@@ -148,10 +169,14 @@ class ODESampler:
     def _phase(self, phase, traj=None, t0=0.0, t_bound=0.0, rtol=1e-5, atol=1e-5, dscale=0.0, do_denoise=1, nstates=0):
         import ctypes
         cd = ctypes.c_double
-        _lib.call("gp_rk45_phase_grouped", phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec), ptr(self.centre),
-                  ptr(self.state), ptr(self.y), ptr(self.ynew), ptr(self.Kbuf), ptr(self.partials), ptr(traj),
-                  0 if traj is None else traj.shape[0], cd(t0), cd(t_bound), cd(rtol), cd(atol), cd(dscale), do_denoise, nstates,
-                  ptr(self.x_out), stream_ptr())
+        tail = (ptr(self.cvec), ptr(self.tvec), ptr(self.centre), ptr(self.state), ptr(self.y), ptr(self.ynew), ptr(self.Kbuf), ptr(self.partials),
+                ptr(traj), 0 if traj is None else traj.shape[0], cd(t0), cd(t_bound), cd(rtol), cd(atol), cd(dscale), do_denoise, nstates,
+                ptr(self.x_out), stream_ptr())
+        if self.ragged:
+            _lib.call("gp_rk45_phase_ragged", phase, self.groups, ptr(self.grp_info), self.nblocks, ptr(self.blk_info), self.tile, self.B, self.K,
+                      self.net.w.ref(), *tail)
+        else:
+            _lib.call("gp_rk45_phase_grouped", phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail)
 
     def _embed(self):
         import ctypes

@@ -239,6 +239,14 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
                           const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
                           double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                           gp_stream_t s);
+/* Ragged variant: groups with different numbers of clouds (tracking: the objects of one frame form a group, frames of different
+ * sequences share the launches).  grp_info [ngroups][4] = {first workgroup, workgroups, rows, first row}; blk_info [nblocks][3] =
+ * {group, first row, end row (exclusive) of the group} per workgroup of `tile` (16 or 32) rows; both device int32.  Rows stay
+ * cloud-major (k rows per cloud), groups occupy consecutive row ranges. */
+int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nblocks, const int32_t *blk_info, int tile, int nclouds_total, int k,
+                         const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state, double *y, double *ynew,
+                         double *K, double *partials, double *traj, int traj_cap, double t0, double t_bound, double rtol, double atol,
+                         double denoise_scale, int do_denoise, int nstates, double *x_out, gp_stream_t s);
 int gp_rk45_set_dense_grouped(int ngroups, void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------

@@ -143,3 +143,60 @@ def test_grouped_ode_predictor_equals_agent():
     for i in range(NB):
         scale = max(1.0, float(seq[i].abs().max()))
         np.testing.assert_allclose(got[i].cpu().numpy(), seq[i].cpu().numpy(), rtol=0, atol=5e-4 * scale, err_msg=f"batch {i}")
+
+
+def test_multi_sequence_tracker_equals_per_sequence_runs():
+    """Frames of three sequences (2, 3 and 1 objects: ragged groups) go through ONE encoder pass / ODE solve / energy pass per step;
+    every sequence gets what its own TrackingRunner gets (same warm starts, same step control: equal evaluation counts)."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.runner import MultiSequenceTracker, TrackingRunner
+    K, T0 = 8, 0.15
+    sa = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"]))
+    sa.load_state_dict(go.make_state_dict(0, "score"))
+    ea = PoseNet(get_config(posenet_mode="energy"))
+    ea.load_state_dict(go.make_state_dict(0, "energy"))
+    counts = [2, 3, 1]
+    gen = torch.Generator().manual_seed(8)
+    n_frames = 3
+    seqs = []
+    for s_, c in enumerate(counts):
+        base = torch.from_numpy(synth.make_batch(c, start=100 * s_ + 3))
+        gt = torch.eye(4).repeat(c, 1, 1)
+        gt[:, :3, 3] = base.mean(dim=1)
+        seqs.append({"pts": [(base + 0.003 * f).cuda() for f in range(n_frames)], "names": [f"s{s_}o{j}" for j in range(c)], "gt": gt})
+    draws = [[[torch.randn(c, generator=gen), torch.randn(c, 4, generator=gen), torch.randn(c, generator=gen), torch.randn(c, 3, generator=gen)]
+              for c in counts] for _ in range(n_frames)]
+    sig = float(go.ve_sigma(torch.tensor(T0)))
+    priors = [[torch.randn(c * K, 9, generator=gen) * sig for c in counts] for _ in range(n_frames)]
+    # reference: one TrackingRunner per sequence
+    ref = []
+    for s_, c in enumerate(counts):
+        tr = TrackingRunner(sa, ea, repeat_num=K, T0=T0)
+        res = []
+        for f in range(n_frames):
+            sa.net.prior_fn = lambda shape, T=1.0, f=f, s_=s_: priors[f][s_]
+            r = tr.step(seqs[s_]["pts"][f], seqs[s_]["names"], seqs[s_]["gt"], noise_draws=draws[f][s_])
+            r["nfev"] = int(sa.net._samplers[("ode", c, K)].last_stats["nfev"])
+            res.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()})
+        ref.append(res)
+    multi = MultiSequenceTracker(sa, ea, len(counts), repeat_num=K, T0=T0)
+    for f in range(n_frames):
+        frames = [(seqs[s_]["pts"][f], seqs[s_]["names"], seqs[s_]["gt"]) for s_ in range(len(counts))]
+        if f == 1:
+            frames[2] = None  # a sequence may skip a step; its warm start must survive
+        got = multi.step(frames, noise_draws=draws[f], prior_noise=priors[f])
+        torch.cuda.synchronize()
+        for s_ in range(len(counts)):
+            if frames[s_] is None:
+                assert got[s_] is None
+                continue
+            if s_ == 2 and f == 2:
+                continue  # sequence 2 skipped frame 1 here but not in its reference run: different warm start by construction
+            r, g = ref[s_][f], got[s_]
+            assert g["nfev"] == r["nfev"], (s_, f, g["nfev"], r["nfev"])
+            np.testing.assert_allclose(g["init_x"].cpu().numpy(), r["init_x"].cpu().numpy(), rtol=0, atol=2e-5)
+            scale = max(1.0, float(r["pred_pose"].abs().max()))
+            np.testing.assert_allclose(g["pred_pose"].cpu().numpy(), r["pred_pose"].cpu().numpy(), rtol=0, atol=5e-4 * scale)
+            np.testing.assert_allclose(g["average_sRT"].cpu().numpy(), r["average_sRT"].cpu().numpy(), rtol=0, atol=2e-3)
