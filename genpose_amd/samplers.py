@@ -188,7 +188,11 @@ class ODESampler:
         self._phase(3, traj)
 
     def _read_states(self):
-        raw_all = self.state.cpu().numpy()  # one D2H copy for all groups
+        if getattr(self, "_state_host", None) is None:
+            self._state_host = torch.empty(self.state.shape, dtype=torch.uint8).pin_memory()
+        self._state_host.copy_(self.state, non_blocking=True)  # one D2H copy for all groups, into pinned memory
+        torch.cuda.current_stream(self.dev).synchronize()
+        raw_all = self._state_host.numpy()
         return [self._parse_state(raw_all[g * self.state_bytes:(g + 1) * self.state_bytes]) for g in range(self.groups)]
 
     def _read_state(self, group=0):
