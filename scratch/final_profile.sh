@@ -15,6 +15,8 @@ timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --sampler od
 timeout 200 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --sampler ode --batches-per-launch 1 > $O/bench_line_ode_g1.json 2>/dev/null
 timeout 300 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --pipeline full --batch 256 > $O/bench_line_full256.json 2>/dev/null
 timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --pipeline full --batch 256 --sampler ode > $O/bench_line_full256_ode.json 2>/dev/null
+timeout 300 python scratch/bench_tracking.py 16 32 64 128 > $O/tracking.txt 2>/dev/null
+timeout 120 python scratch/bench_pre.py 6 > $O/preprocess.txt 2>/dev/null; timeout 120 python scratch/bench_pre.py 64 >> $O/preprocess.txt 2>/dev/null
 for B in 64 320; do
   timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$B -o run -- python scratch/microbench.py $B 50 > $O/pmc_fetch_$B.log 2>&1
   timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$B -o run -- python scratch/microbench.py $B 50 > $O/pmc_write_$B.log 2>&1
