@@ -1,8 +1,16 @@
-"""Two-stream software pipeline over batches: the encoder of batch i+1 runs on one HIP stream while the T-step sampler
-hipGraph of batch i runs on another.  The sampler's launches occupy at most ceil(R/16) workgroups (200 of 256 CUs at the
-bench configuration) and stall on every step boundary; the encoder's thousands of workgroups fill those holes.  Batches
-are independent, so this changes throughput only - every batch's result is identical to the sequential
-`PoseNet.pred_func` (asserted in tests/test_gpu_pipeline.py).
+"""Serving a stream of equally-shaped batches (throughput mode): request batching and stream pipelining around the agents'
+kernels.  Three predictors, all returning per batch exactly what the sequential `PoseNet.pred_func` returns for it (asserted in
+tests/test_gpu_pipeline.py):
+
+  PipelinedPCPredictor  encoder + PC sampler.  `batches_per_launch` consecutive batches share one encoder pass and one sampler
+                        launch chain (the sampler's batch-global coupling stays per batch, gp_pc_step_grouped); optionally the
+                        encoder of the next group runs on a second HIP stream under the sampler graph of the current one
+                        (`overlap`), and its furthest point sampling always runs ahead on a side stream (`fps_ahead`).
+  GroupedODEPredictor   encoder + PF-ODE sampler, several batches per launch of the device-resident RK45 driver, one step
+                        controller per batch (gp_rk45_phase_grouped).
+  (runner.MultiSequenceTracker does the same for tracking, with ragged groups.)
+
+Host code in these loops is allocation-free and keeps its CPU tensor ops single-threaded (see _randn_1t).
 """
 import torch
 
