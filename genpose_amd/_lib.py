@@ -50,6 +50,7 @@ SIGNATURES = {
     "gp_roi_to_cloud": [c_int, c_int, c_int, c_int, P, P, P, c_float, c_float, c_float, c_float, P, P, P, P],
     "gp_cloud_sample": [c_int, c_int, c_int, P, P, P, P, P],
     "gp_score_div": [c_int, c_int, NETP, P, P, P, P, P, P, P, P],
+    "gp_energy_score": [c_int, c_int, NETP, P, P, P, P, P, P, P],
     "gp_pc_tile_rows": [c_int, c_int, c_int],
     "gp_pc_step_grouped": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
     "gp_rk45_state_bytes": [],

@@ -39,6 +39,10 @@ __device__ __forceinline__ void backward_dense(const float *Gin, int ldg, const 
     }
 }
 
+// MODE 0 (likelihood):      u = eps / (sigma + 1e-7);  score = f / (sigma + 1e-7);  div = (J_f^T u) . eps
+// MODE 1 (energy gradient): probe = x, u = x / sigma;   score = f / sigma + J_f^T u  (= d/dx <x, f(x)/sigma>, energynet.py:200-222);
+//                           div = <x, f / sigma> (the un-decoupled IP energy)
+template <int MODE>
 __global__ __launch_bounds__(DNT) void score_div_kernel(int nrows, int kcand, gp_scorenet net, const float *__restrict__ cvec,
                                                         const float *__restrict__ tvec, const float *__restrict__ x, const float *__restrict__ eps,
                                                         const float *__restrict__ sigma_dev, float *__restrict__ score, float *__restrict__ div) {
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(DNT) void score_div_kernel(int nrows, int kcand, gp
         if (g >= nrows) g = nrows - 1;
         const float ev = j < POSE ? eps[(size_t)g * POSE + j] : 0.f;
         E[e] = ev;
-        U[e] = ev / (sigma + 1e-7f);
+        U[e] = MODE == 0 ? ev / (sigma + 1e-7f) : ev / sigma;
     }
     __syncthreads();
     // forward; every head-layer fragment leaves its backward seed in G3 (same lane layout as the activations: one b128 store)
@@ -72,10 +76,12 @@ __global__ __launch_bounds__(DNT) void score_div_kernel(int nrows, int kcand, gp
                                g.w = a3.w > 0.f ? (w0.w * u0 + w1.w * u1) + w2.w * u2 : 0.f;
                                *reinterpret_cast<f32x4 *>(G3 + (lane & 15) * LDG + ch) = g;
                            });
-    // score out (f_theta parked in X0 columns 12..20 by KEEP_H1)
-    for (int e = tid; e < DP * POSE; e += DNT) {
-        const int r = e / POSE, j = e - r * POSE;
-        if (row0 + r < nrows) score[(size_t)(row0 + r) * POSE + j] = X0[r * L::LD0 + 12 + j] / (sigma + 1e-7f);
+    // score out (f_theta parked in X0 columns 12..20 by KEEP_H1); MODE 1 adds the vector-Jacobian product at the end
+    if (MODE == 0) {
+        for (int e = tid; e < DP * POSE; e += DNT) {
+            const int r = e / POSE, j = e - r * POSE;
+            if (row0 + r < nrows) score[(size_t)(row0 + r) * POSE + j] = X0[r * L::LD0 + 12 + j] / (sigma + 1e-7f);
+        }
     }
     // ---- backward: g2 = (Wx^T g3) . [h2 > 0]  -> over H2;  g1 = (W2^T g2) . [h1 > 0]  -> over H1   (trunk_ftheta ended on a barrier)
     backward_dense<HEADS / 16>(G3, LDG, net.w_headx_t, H2, L::LDH);
@@ -88,12 +94,31 @@ __global__ __launch_bounds__(DNT) void score_div_kernel(int nrows, int kcand, gp
         f32x4 acc[4][1];
         mfma_tile<1, 1>(H1, L::LDH, 0, net.w_pose0_t, HID / 16, 1, nc, acc);
         const float *e = E + (lane & 15) * 12 + 4 * (lane >> 4);  // channels 4g..4g+3 (zero beyond 8)
-        float d = 0.f;
-        if ((lane >> 4) < 3) d = acc[0][0].x * e[0] + acc[0][0].y * e[1] + acc[0][0].z * e[2] + acc[0][0].w * e[3];
-        // lanes l, l+16, l+32 hold the three channel groups of row l: sum them (group 3 holds zeros)
-        d += __shfl_xor(d, 16, 64);
-        d += __shfl_xor(d, 32, 64);
-        if (lane < 16 && row0 + lane < nrows) div[row0 + lane] = d;
+        if (MODE == 0) {
+            float d = 0.f;
+            if ((lane >> 4) < 3) d = acc[0][0].x * e[0] + acc[0][0].y * e[1] + acc[0][0].z * e[2] + acc[0][0].w * e[3];
+            // lanes l, l+16, l+32 hold the three channel groups of row l: sum them (group 3 holds zeros)
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            if (lane < 16 && row0 + lane < nrows) div[row0 + lane] = d;
+        } else {
+            // score = f / sigma + J^T u per component; energy = <x, f / sigma>
+            const int r = lane & 15, g = lane >> 4;
+            const float gx[4] = {acc[0][0].x, acc[0][0].y, acc[0][0].z, acc[0][0].w};
+            float en = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * g + q;
+                if (j < POSE) {
+                    const float s = X0[r * L::LD0 + 12 + j] / sigma;
+                    en += e[q] * s;
+                    if (row0 + r < nrows) score[(size_t)(row0 + r) * POSE + j] = s + gx[q];
+                }
+            }
+            en += __shfl_xor(en, 16, 64);
+            en += __shfl_xor(en, 32, 64);
+            if (div && lane < 16 && row0 + lane < nrows) div[row0 + lane] = en;
+        }
     }
 }
 
@@ -108,10 +133,28 @@ extern "C" int gp_score_div(int nclouds, int k, const gp_scorenet *net, const fl
     const size_t lds = (size_t)DIV_LDS_FLOATS * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(score_div_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(score_div_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(score_div_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return GP_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(score_div_kernel, dim3((R + DP - 1) / DP), dim3(DNT), lds, (hipStream_t)s, R, k, *net, cvec, tvec, x, eps, sigma_dev, score, div);
+    hipLaunchKernelGGL(score_div_kernel<0>, dim3((R + DP - 1) / DP), dim3(DNT), lds, (hipStream_t)s, R, k, *net, cvec, tvec, x, eps, sigma_dev, score, div);
+    return gp_launch_status();
+}
+
+extern "C" int gp_energy_score(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x, const float *sigma_dev,
+                               float *score, float *energy, gp_stream_t s) {
+    if (nclouds < 0 || k <= 0 || !net || !cvec || !tvec || !x || !sigma_dev || !score) return GP_EINVAL;
+    if (!net->w_headx_t || !net->w_pose2_t || !net->w_pose0_t) return GP_EINVAL;
+    const int R = nclouds * k;
+    if (R == 0) return GP_OK;
+    const size_t lds = (size_t)DIV_LDS_FLOATS * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(score_div_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GP_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(score_div_kernel<1>, dim3((R + DP - 1) / DP), dim3(DNT), lds, (hipStream_t)s, R, k, *net, cvec, tvec, x, x, sigma_dev, score, energy);
     return gp_launch_status();
 }

@@ -151,9 +151,16 @@ class GFObjectPose:
             return self.extract_pts_feature(data)
         if mode in ("score", "energy"):
             self._need_weights()
-            if (mode == "energy") != (self.cfg.posenet_mode == "energy"):
-                raise NotImplementedError("score-from-energy (autograd) and energy-from-score paths are outside the inference hot path")
+            if mode == "energy" and self.cfg.posenet_mode != "energy":
+                raise NotImplementedError("an energy from the score model does not exist in the reference either (posenet.py:154-160)")
             K = int(data.get("_repeat", 1))
+            if mode == "score" and self.cfg.posenet_mode == "energy":
+                # score of the energy model: gradient of the inner-product energy w.r.t. the pose (energynet.py:200-222)
+                cvec = self.pose_score_net.cloud_embed(data["pts_feat"].float())
+                t0 = data["t"].reshape(-1)[:1].float().contiguous()
+                tvec = self.pose_score_net.time_embed(t0)
+                sigma = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t0).contiguous()
+                return self.pose_score_net.energy_score(cvec, K, data["sampled_pose"].float().contiguous(), tvec[0], sigma)
             if K == 1:
                 return self.pose_score_net.forward_rows(data["pts_feat"], data["sampled_pose"], data["t"], mode)
             cvec = self.pose_score_net.cloud_embed(data["pts_feat"].float())

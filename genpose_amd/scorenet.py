@@ -57,6 +57,15 @@ class ScoreNetHIP:
         _lib.call("gp_score_div", B, k, self.w.ref(), ptr(cvec), ptr(tvec), ptr(x), ptr(eps), ptr(sigma_dev), ptr(score), ptr(div), stream_ptr())
         return score, div
 
+    def energy_score(self, cvec, k, x, tvec, sigma_dev, with_energy=False):
+        """Score of the energy model = d/dx <x, f(x)/sigma> [B*k,9] (+ that energy [B*k]) in one launch (gp_energy_score)."""
+        _lib.check_device()
+        R = cvec.shape[0] * k
+        score = torch.empty(R, 9, device=self.device)
+        energy = torch.empty(R, device=self.device) if with_energy else None
+        _lib.call("gp_energy_score", cvec.shape[0], k, self.w.ref(), ptr(cvec), ptr(tvec), ptr(x), ptr(sigma_dev), ptr(score), ptr(energy), stream_ptr())
+        return (score, energy) if with_energy else score
+
     def forward_rows(self, pts_feat_rows, pose, t, mode="score"):
         """Reference-shaped call: pts_feat [R,1024] (one feature row per pose row), pose [R,9], t [R,1] (uniform)."""
         tt = t.reshape(-1)

@@ -176,6 +176,12 @@ int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec,
 int gp_score_div(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x, const float *eps,
                  const float *sigma_dev, float *score, float *div, gp_stream_t s);
 
+/* Score of the ENERGY model (PoseEnergyNet.forward(return_item='score'), energynet.py:200-222): the gradient of the un-decoupled
+ * inner-product energy <x, f_theta(x)/sigma> with respect to the pose, which the reference obtains by autograd:
+ *   score[R,9] = f_theta/sigma + J_f^T (x/sigma);  energy[R] (may be NULL) = <x, f_theta/sigma>.  `net` = the energy net's block. */
+int gp_energy_score(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x, const float *sigma_dev,
+                    float *score, float *energy, gp_stream_t s);
+
 /* Rows per workgroup tile of the score kernels (size of `partials` = nsteps * ceil(R / tile)). */
 int gp_score_tile_rows(int nrows);
 

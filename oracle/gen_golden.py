@@ -371,7 +371,28 @@ def main_g12():
     print("g12_likelihood.npz", ll.numpy(), "nfev", nfev)
 
 
+def main_g13():
+    """G13 score of the energy model: PoseEnergyNet.forward(return_item='score') of the imported reference (energynet.py:200-222)
+    through GFObjectPose.forward(mode='score') with posenet_mode='energy' (posenet.py:154-157)."""
+    ns = ref_import.load()
+    ag, sd = make_agent(ns, "energy")
+    gen = torch.Generator().manual_seed(13)
+    pf = torch.randn(6, 1024, generator=gen).abs()
+    pose = torch.randn(6, 9, generator=gen)
+    g13 = {"pts_feat": pf.numpy(), "pose": pose.numpy(), "t": np.array([1e-5, 0.15, 0.7])}
+    for i, t in enumerate(g13["t"]):
+        data = {"pts_feat": pf.clone(), "sampled_pose": pose.clone(), "t": torch.ones(6, 1) * float(t)}
+        sc = ag.net(data, mode="score").detach()
+        ref_s, ref_e = go.energy_score(sd, pf, pose, torch.ones(6, 1) * float(t))
+        assert np.allclose(sc.numpy(), ref_s.numpy(), rtol=1e-5, atol=1e-5 * float(ref_s.abs().max()))
+        g13[f"score_{i}"] = sc.numpy()
+    np.savez_compressed(os.path.join(OUT, "g13_energy_score.npz"), **g13)
+    print("g13_energy_score.npz", os.path.getsize(os.path.join(OUT, "g13_energy_score.npz")))
+
+
 if __name__ == "__main__":
+    if "--g13" in sys.argv:
+        sys.exit(main_g13())
     if "--g12" in sys.argv:
         sys.exit(main_g12())
     sys.exit(main_g11() if "--g11" in sys.argv else (main_g10() if "--g10" in sys.argv else main()))

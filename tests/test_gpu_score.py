@@ -88,3 +88,45 @@ def test_score_and_divergence_vs_autograd(nets, B, K):
         # same score as the plain evaluation
         s0 = snet.evaluate(cvec, K, pose.cuda(), tvec[0], sigma, "score")
         np.testing.assert_allclose(s.cpu().numpy(), s0.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(ref_s.abs().max()))
+
+
+def test_energy_model_score_golden(nets, golden):
+    """Score of the energy model (energynet.py:200-222, autograd in the reference) against the imported reference (fixture G13)
+    and against the oracle's autograd on larger, ragged shapes."""
+    _, enet = nets
+    g = golden("g13_energy_score.npz")
+    pf, pose = torch.from_numpy(g["pts_feat"]).cuda(), torch.from_numpy(g["pose"]).cuda()
+    for i, t in enumerate(g["t"]):
+        cvec = enet.cloud_embed(pf)
+        tvec = enet.time_embed(torch.tensor([float(t)], device="cuda"))
+        sigma = torch.tensor([0.01 * 5000.0 ** float(t)], device="cuda")
+        s = enet.energy_score(cvec, 1, pose, tvec[0], sigma).cpu().numpy()
+        np.testing.assert_allclose(s, g[f"score_{i}"], rtol=NET_RTOL, atol=NET_RTOL * np.abs(g[f"score_{i}"]).max())
+    sd = go.make_state_dict(0, "energy")
+    gen = torch.Generator().manual_seed(31)
+    for B, K in [(3, 7), (5, 50)]:
+        pfc = torch.randn(B, 1024, generator=gen).abs()
+        x = torch.randn(B * K, 9, generator=gen)
+        t = 0.3
+        ref_s, ref_e = go.energy_score(sd, pfc.repeat_interleave(K, 0), x, torch.ones(B * K, 1) * t)
+        cvec = enet.cloud_embed(pfc.cuda())
+        tvec = enet.time_embed(torch.tensor([t], device="cuda"))
+        sigma = torch.tensor([0.01 * 5000.0 ** t], device="cuda")
+        s, e = enet.energy_score(cvec, K, x.cuda(), tvec[0], sigma, with_energy=True)
+        np.testing.assert_allclose(s.cpu().numpy(), ref_s.numpy(), rtol=NET_RTOL, atol=NET_RTOL * float(ref_s.abs().max()))
+        np.testing.assert_allclose(e.cpu().numpy(), ref_e.numpy(), rtol=NET_RTOL, atol=NET_RTOL * float(ref_e.abs().max()))
+
+
+def test_energy_agent_score_mode():
+    """GFObjectPose.forward(mode='score') on the energy agent (posenet.py:154-157) returns that gradient."""
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    ea = PoseNet(get_config(posenet_mode="energy"))
+    sd = go.make_state_dict(0, "energy")
+    ea.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(2)
+    pf, pose = torch.randn(4, 1024, generator=gen).abs(), torch.randn(4, 9, generator=gen)
+    data = {"pts_feat": pf.cuda(), "sampled_pose": pose.cuda(), "t": torch.ones(4, 1, device="cuda") * 0.2}
+    got = ea.net(data, mode="score").cpu().numpy()
+    ref, _ = go.energy_score(sd, pf, pose, torch.ones(4, 1) * 0.2)
+    np.testing.assert_allclose(got, ref.numpy(), rtol=NET_RTOL, atol=NET_RTOL * float(ref.abs().max()))

@@ -165,3 +165,12 @@ def test_likelihood_oracle_equals_reference(golden):
     assert nfev == int(g["nfev"])
     np.testing.assert_allclose(ll.numpy(), g["log_likelihood"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(z.numpy(), g["z"], rtol=1e-9, atol=1e-9)
+
+
+def test_energy_score_oracle_equals_reference(golden):
+    g = golden("g13_energy_score.npz")
+    sd = go.make_state_dict(0, "energy")
+    pf, pose = torch.from_numpy(g["pts_feat"]), torch.from_numpy(g["pose"])
+    for i, t in enumerate(g["t"]):
+        s, _ = go.energy_score(sd, pf, pose, torch.ones(6, 1) * float(t))
+        np.testing.assert_allclose(s.numpy(), g[f"score_{i}"], rtol=1e-5, atol=1e-5 * np.abs(g[f"score_{i}"]).max())
