@@ -9,6 +9,8 @@ DEFAULTS = dict(
     energy_mode="IP", s_theta_mode="score", norm_energy="identical", eval_repeat_num=50, batch_size=192, T0=1.0,
     pooling_mode="nearest", ranker="energy_ranker", score_model_dir="", energy_model_dir="", result_dir="", test_source="Real",
     save_video=False, is_train=False, use_pretrain=False, log_dir="debug", parallel=False, seed=0,
+    # pre-processing / evaluation side (preprocess.py, evaluation.py): configs/config.py:8,72-78
+    synset_names=["bottle", "bowl", "camera", "can", "laptop", "mug"], img_size=256, max_eval_num=10000000, results_path="",
 )
 
 
