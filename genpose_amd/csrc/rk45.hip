@@ -113,6 +113,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
     const int tid = threadIdx.x;
     int grp, row0, rend;
     ode_block<P>(a, grp, row0, rend);
+    if (row0 >= rend) return;  // padding workgroup of a ragged launch (tables sized for a capacity)
     Rk45State *st = a.st + grp;
     if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
     const size_t n = (size_t)a.nrows * 9;
@@ -241,6 +242,10 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
     const int nblk = a.grp_info ? a.grp_info[4 * blockIdx.x + 1] : a.bpg;
     const int grows = a.grp_info ? a.grp_info[4 * blockIdx.x + 2] : a.rows_per_group;
     const double *part = a.partials + blk0;
+    if (grows <= 0) {  // padding group of a ragged launch: nothing to integrate
+        if (threadIdx.x == 0) st->status = 1;
+        return;
+    }
     const double nn = (double)grows * 9.0;
     if (mode == 0) {
         const double s0 = sum_partials(part, nblk, sh);
@@ -324,6 +329,7 @@ __global__ void rk45_record_kernel(OdeArgs a) {
     const size_t g_row0 = a.grp_info ? a.grp_info[4 * blockIdx.y + 3] : (size_t)blockIdx.y * a.rows_per_group;
     const size_t g_rows = a.grp_info ? a.grp_info[4 * blockIdx.y + 2] : a.rows_per_group;
     const size_t e_lo = g_row0 * 9, e_hi = e_lo + g_rows * 9;
+    if (g_rows == 0) return;
     if (st->n_eval > 0) {
         // 4th-order dense output of the step just accepted (rk.py RkDenseOutput): y(t) = y_old + h * Q . [x, x^2, x^3, x^4],
         // Q = K^T P, x = (t - t_old) / h.  y is still y_old here (the commit happens in the next attempt's first stage).
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
     const int tid = threadIdx.x;
     int grp, row0, rend;
     ode_block<P>(a, grp, row0, rend);
+    if (row0 >= rend) return;
     const Rk45State *st = a.st + grp;
     const double *yfin = st->last_accepted ? a.ynew : a.y;
     const float *tvec = a.tvec + (size_t)grp * 8 * HEADS;  // slot 0 = eps

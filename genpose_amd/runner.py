@@ -162,11 +162,14 @@ class MultiSequenceTracker:
     ranking launch.  Per sequence the semantics are TrackingRunner's: warm start from the previous frame's aggregated pose
     of the same `model_name`, else the jittered ground truth; T0 = 0.15."""
 
-    def __init__(self, score_agent, energy_agent, n_sequences, repeat_num=50, T0=0.15, ratio=0.6):
+    def __init__(self, score_agent, energy_agent, n_sequences, repeat_num=50, T0=0.15, ratio=0.6, max_objects_per_frame=8):
         self.score_agent, self.energy_agent = score_agent, energy_agent
         self.repeat_num, self.T0, self.ratio = repeat_num, T0, ratio
         self.buffers = [{"model_name": [], "pred_sRT": None} for _ in range(n_sequences)]
-        self._samplers = {}
+        # one solver sized for the capacity; the group tables are re-filled every step, so frames whose object counts change
+        # keep replaying the same captured graphs
+        self.cap_groups, self.cap_clouds = n_sequences, n_sequences * max_objects_per_frame
+        self._sampler = None
 
     def reset(self, seq=None):
         for i in (range(len(self.buffers)) if seq is None else [seq]):
@@ -217,10 +220,13 @@ class MultiSequenceTracker:
         else:
             pr = torch.cat([prior_noise[i].reshape(-1, 9) for i in live], dim=0).to(dev).float()
         x0 = init_x.unsqueeze(1).repeat(1, K, 1).reshape(B * K, 9).float() + pr
-        key = tuple(counts)
-        smp = self._samplers.get(key)
+        if B > self.cap_clouds:
+            raise ValueError(f"{B} objects in this step exceed the capacity {self.cap_clouds} (n_sequences x max_objects_per_frame)")
+        smp = self._sampler
         if smp is None:
-            smp = self._samplers[key] = ODESampler(net.pose_score_net, B, K, dev, group_clouds=counts)
+            per = self.cap_clouds // self.cap_groups
+            smp = self._sampler = ODESampler(net.pose_score_net, self.cap_clouds, K, dev, group_clouds=[per] * self.cap_groups)
+        smp.set_groups(counts)
         _, x = smp.run(cvec, centre, x0, self.T0, num_steps=net.cfg.sampling_steps, eps=net.sampling_eps)
         pred = x.reshape(B, K, 9)
         # ---- energy model + ranking + aggregation for all clouds at once (row / cloud local)

@@ -122,24 +122,15 @@ class ODESampler:
         self.ragged = group_clouds is not None
         self.dev = torch.device(device)
         if self.ragged:
-            # groups of different sizes (tracking: the objects of one frame): consecutive cloud ranges, 16-row tiles that end at
-            # the group boundary (gp_rk45_phase_ragged)
-            group_clouds = [int(c) for c in group_clouds]
-            if sum(group_clouds) != B or min(group_clouds) <= 0:
-                raise ValueError(f"group sizes {group_clouds} do not add up to {B} clouds")
+            # groups of different sizes (tracking: the objects of one frame): consecutive cloud ranges, tiles that end at the group
+            # boundary (gp_rk45_phase_ragged).  B and len(group_clouds) are CAPACITIES: set_groups() re-fills the device tables for
+            # any grouping that fits, so the captured graphs (fixed grids) serve frames whose object counts change.
             groups = len(group_clouds)
             self.tile = _lib.lib().gp_score_tile_rows(B * K)  # 16 rows, or 32 once the launch is big enough to be MFMA-bound
-            blk, grp, row = [], [], 0
-            for g, c in enumerate(group_clouds):
-                rows = c * K
-                nb = (rows + self.tile - 1) // self.tile
-                grp.append([len(blk), nb, rows, row])
-                blk += [[g, row + i * self.tile, row + rows] for i in range(nb)]
-                row += rows
-            self.nblocks = len(blk)
-            self.blk_info = torch.tensor(blk, dtype=torch.int32, device=self.dev)
-            self.grp_info = torch.tensor(grp, dtype=torch.int32, device=self.dev)
-            self.group_clouds = group_clouds
+            self.nblocks = (B * K + self.tile - 1) // self.tile + groups  # every group wastes less than one tile
+            self.blk_info = torch.zeros(self.nblocks, 3, dtype=torch.int32, device=self.dev)
+            self.grp_info = torch.zeros(groups, 4, dtype=torch.int32, device=self.dev)
+            self._tables_host = (torch.zeros(self.nblocks, 3, dtype=torch.int32).pin_memory(), torch.zeros(groups, 4, dtype=torch.int32).pin_memory())
         elif B % groups:
             raise ValueError(f"{B} clouds do not split into {groups} equal batches")
         self.net, self.B, self.K, self.groups = net, B, K, groups
@@ -149,6 +140,8 @@ class ODESampler:
             if self.tile < 0:
                 raise ValueError(f"{B // groups} clouds x {K} candidates per batch is not a multiple of the 16-row tile; run the batches separately")
             self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
+        if self.ragged:
+            self.set_groups(group_clouds)
         self.layout, nbytes = _state_layout()
         self.state_bytes = nbytes
         self.state = torch.zeros(groups * nbytes, dtype=torch.uint8, device=self.dev)
@@ -165,6 +158,32 @@ class ODESampler:
         self.graph_traj = None
         self.graph_dense = None
         self.last_stats = {}
+
+    def set_groups(self, group_clouds):
+        """Ragged mode: (re)define the groups - clouds per group, consecutive; fewer groups / clouds than the capacity leave padding
+        workgroups and padding groups that exit at once.  Returns the number of clouds in use."""
+        group_clouds = [int(c) for c in group_clouds]
+        if len(group_clouds) > self.groups or sum(group_clouds) > self.B or (group_clouds and min(group_clouds) <= 0):
+            raise ValueError(f"groups {group_clouds} exceed the capacity ({self.groups} groups, {self.B} clouds)")
+        blk_h, grp_h = self._tables_host
+        torch.cuda.current_stream(self.dev).synchronize()  # previous launches (and table uploads) have finished
+        blk, grp = blk_h.numpy(), grp_h.numpy()
+        blk[:] = 0
+        grp[:] = 0
+        if group_clouds:
+            rows = np.asarray(group_clouds, dtype=np.int64) * self.K
+            nb = (rows + self.tile - 1) // self.tile
+            row0 = np.concatenate([[0], np.cumsum(rows)[:-1]])
+            blk0 = np.concatenate([[0], np.cumsum(nb)[:-1]])
+            ng = len(group_clouds)
+            grp[:ng] = np.stack([blk0, nb, rows, row0], axis=1)
+            gid = np.repeat(np.arange(ng), nb)
+            local = np.arange(int(nb.sum())) - np.repeat(blk0, nb)
+            blk[: len(gid)] = np.stack([gid, row0[gid] + local * self.tile, (row0 + rows)[gid]], axis=1)
+        self.blk_info.copy_(blk_h, non_blocking=True)
+        self.grp_info.copy_(grp_h, non_blocking=True)
+        self.group_clouds = group_clouds
+        return sum(group_clouds)
 
     def _phase(self, phase, traj=None, t0=0.0, t_bound=0.0, rtol=1e-5, atol=1e-5, dscale=0.0, do_denoise=1, nstates=0):
         import ctypes
@@ -215,9 +234,10 @@ class ODESampler:
         dense = return_process and num_steps is not None
         if self.groups > 1 and return_process and not dense:
             raise NotImplementedError("accepted-state trajectories have a different length per batch: ask for them one batch at a time")
-        self.cvec.copy_(cvec)
-        self.centre.copy_(centre)
-        self.y.copy_(init_x.reshape(-1).double())  # init_x f32 -> f64 state (solve_ivp casts y0 to float64)
+        nb_in = cvec.shape[0]  # ragged mode may use fewer clouds than the capacity
+        self.cvec[:nb_in].copy_(cvec)
+        self.centre[:nb_in].copy_(centre)
+        self.y[: nb_in * self.K * 9].copy_(init_x.reshape(-1).double())  # init_x f32 -> f64 state (solve_ivp casts y0 to float64)
         traj = None
         if dense:
             # solve_ivp(t_eval=np.linspace(T0, eps, num_steps)): 4th-order dense output at every t_eval point
@@ -262,6 +282,8 @@ class ODESampler:
                     self._attempt(traj)
             n_done += self.poll
             sts = self._read_states()
+            if self.ragged:
+                sts = sts[: len(self.group_clouds)]
             if all(s_["status"] != 0 for s_ in sts):
                 break
             if n_done >= max_attempts:
@@ -283,4 +305,4 @@ class ODESampler:
         xs = None
         if traj is not None:
             xs = traj[:nstates].reshape(nstates, self.R, 9).permute(1, 0, 2).clone()
-        return xs, self.x_out.clone()
+        return xs, self.x_out[: nb_in * self.K].clone()

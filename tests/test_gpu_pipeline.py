@@ -200,3 +200,45 @@ def test_multi_sequence_tracker_equals_per_sequence_runs():
             scale = max(1.0, float(r["pred_pose"].abs().max()))
             np.testing.assert_allclose(g["pred_pose"].cpu().numpy(), r["pred_pose"].cpu().numpy(), rtol=0, atol=5e-4 * scale)
             np.testing.assert_allclose(g["average_sRT"].cpu().numpy(), r["average_sRT"].cpu().numpy(), rtol=0, atol=2e-3)
+
+
+def test_multi_sequence_tracker_changing_object_counts():
+    """Object counts change from frame to frame (objects enter and leave): the tracker's one capacity-sized solver re-fills its
+    group tables per step; each sequence still equals its own TrackingRunner."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.runner import MultiSequenceTracker, TrackingRunner
+    K, T0 = 8, 0.15
+    sa = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"]))
+    sa.load_state_dict(go.make_state_dict(0, "score"))
+    ea = PoseNet(get_config(posenet_mode="energy"))
+    ea.load_state_dict(go.make_state_dict(0, "energy"))
+    gen = torch.Generator().manual_seed(18)
+    plan = [[3, 1], [2, 2], [4, 1]]  # objects per sequence per frame: a prefix of each sequence's object list
+    pools = [torch.from_numpy(synth.make_batch(4, start=200 * s_)) for s_ in range(2)]
+    sig = float(go.ve_sigma(torch.tensor(T0)))
+    multi = MultiSequenceTracker(sa, ea, 2, repeat_num=K, T0=T0, max_objects_per_frame=4)
+    singles = [TrackingRunner(sa, ea, repeat_num=K, T0=T0) for _ in range(2)]
+    smp_id = None
+    for f, counts in enumerate(plan):
+        frames, draws, priors = [], [], []
+        for s_, c in enumerate(counts):
+            pts = (pools[s_][:c] + 0.002 * f).cuda()
+            gt = torch.eye(4).repeat(c, 1, 1)
+            gt[:, :3, 3] = pools[s_][:c].mean(dim=1)
+            frames.append((pts, [f"s{s_}o{j}" for j in range(c)], gt))
+            draws.append([torch.randn(c, generator=gen), torch.randn(c, 4, generator=gen), torch.randn(c, generator=gen), torch.randn(c, 3, generator=gen)])
+            priors.append(torch.randn(c * K, 9, generator=gen) * sig)
+        got = multi.step(frames, noise_draws=draws, prior_noise=priors)
+        torch.cuda.synchronize()
+        assert smp_id in (None, id(multi._sampler))  # one solver for every grouping
+        smp_id = id(multi._sampler)
+        for s_, c in enumerate(counts):
+            sa.net.prior_fn = lambda shape, T=1.0, s_=s_: priors[s_]
+            r = singles[s_].step(frames[s_][0], frames[s_][1], frames[s_][2], noise_draws=draws[s_])
+            nfev = int(sa.net._samplers[("ode", c, K)].last_stats["nfev"])
+            assert got[s_]["nfev"] == nfev, (f, s_, got[s_]["nfev"], nfev)
+            scale = max(1.0, float(r["pred_pose"].abs().max()))
+            np.testing.assert_allclose(got[s_]["pred_pose"].cpu().numpy(), r["pred_pose"].cpu().numpy(), rtol=0, atol=5e-4 * scale)
+            np.testing.assert_allclose(got[s_]["average_sRT"].cpu().numpy(), r["average_sRT"].cpu().numpy(), rtol=0, atol=2e-3)
