@@ -124,45 +124,37 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
     const double h = st->h;
     const float sigma = st->stage_sigma[slot];  // requested now, used after the trunk
     const double g2 = st->stage_g2[slot];
-    if (tid < P) {
-        const bool live = row0 + tid < rend;
-        const int r = live ? row0 + tid : rend - 1;
-        double ys[9];
-        if (STAGE == 1 && st->last_accepted) {
-            // commit the previous accepted step for this tile's rows (row-local: no other block touches them)
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const size_t e = (size_t)r * 9 + j;
-                const double v = a.ynew[e];
-                if (live) {
-                    a.y[e] = v;
-                    a.K[e] = a.K[6 * n + e];
-                }
-            }
+    // stage input, one (row, component) element per thread: y (+ h * sum_q a_sq K_q) in f64 -> f32 network input in LDS
+    for (int e = tid; e < P * 16; e += TrunkCfg<P>::NT) {
+        const int rr = e >> 4, j = e & 15;
+        float *xr = lds + rr * L::LD0;
+        if (j >= POSE) {
+            xr[j] = 0.f;
+            continue;
         }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const size_t e = (size_t)r * 9 + j;
-            double yv = (STAGE == 1 && st->last_accepted) ? a.ynew[e] : a.y[e];
-            if (STAGE >= 1 && STAGE <= 6) {
-                double dy = 0.0;
-#pragma unroll
-                for (int q = 0; q < STAGE; ++q) {
-                    const double kq = (q == 0 && STAGE == 1 && st->last_accepted) ? a.K[6 * n + e] : a.K[(size_t)q * n + e];
-                    dy += kq * DP_A[STAGE][q];
-                }
-                yv = yv + dy * h;  // rk.py: dy = dot(K[:s].T, a[:s]) * h ; y + dy   (stage 6: y + h * dot(K[:-1].T, B))
-                if (STAGE == 6 && live) a.ynew[e] = yv;
-            } else if (STAGE == 7) {
-                yv = yv + st->h0 * st->direction * a.K[e];  // common.py: y1 = y0 + h0 * direction * f0
-            }
-            ys[j] = yv;
+        const bool live = row0 + rr < rend;
+        const int r = live ? row0 + rr : rend - 1;  // rows past the end: clamped duplicates (computed, never stored)
+        const size_t ge = (size_t)r * 9 + j;
+        const bool commit = STAGE == 1 && st->last_accepted;
+        double yv = commit ? a.ynew[ge] : a.y[ge];
+        if (commit && live) {
+            // commit the previous accepted step for this element (element-local: no other thread touches it)
+            a.y[ge] = yv;
+            a.K[ge] = a.K[6 * n + ge];
         }
-        float *xr = lds + tid * L::LD0;
+        if (STAGE >= 1 && STAGE <= 6) {
+            double dy = 0.0;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) xr[j] = (float)ys[j];  // torch.tensor(x, dtype=float32) (samplers.py:191)
-#pragma unroll
-        for (int j = 9; j < 16; ++j) xr[j] = 0.f;
+            for (int q = 0; q < STAGE; ++q) {
+                const double kq = (q == 0 && commit) ? a.K[6 * n + ge] : a.K[(size_t)q * n + ge];
+                dy += kq * DP_A[STAGE][q];
+            }
+            yv = yv + dy * h;  // rk.py: dy = dot(K[:s].T, a[:s]) * h ; y + dy   (stage 6: y + h * dot(K[:-1].T, B))
+            if (STAGE == 6 && live) a.ynew[ge] = yv;
+        } else if (STAGE == 7) {
+            yv = yv + st->h0 * st->direction * a.K[ge];  // common.py: y1 = y0 + h0 * direction * f0
+        }
+        xr[j] = (float)yv;  // torch.tensor(x, dtype=float32) (samplers.py:191)
     }
     __syncthreads();
     trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre);
