@@ -60,11 +60,13 @@ __device__ __forceinline__ void layer3_max(const SAArgs &a, const float *A, int 
                     m.w = row16_max(m.w);
                     if ((lane & 15) == 0 && ch < a.c3) {
                         if (a.groupall) {
-                            unsigned int *o = reinterpret_cast<unsigned int *>(outb + ch);
-                            atomicMax(o + 0, __float_as_uint(m.x));
-                            atomicMax(o + 1, __float_as_uint(m.y));
-                            atomicMax(o + 2, __float_as_uint(m.z));
-                            atomicMax(o + 3, __float_as_uint(m.w));
+                            // post-ReLU values are >= 0, so their bit patterns order like SIGNED integers; a signed max also
+                            // keeps a stray -0.0f (0x80000000 = INT_MIN) below the zero-initialised buffer
+                            int *o = reinterpret_cast<int *>(outb + ch);
+                            atomicMax(o + 0, __float_as_int(m.x));
+                            atomicMax(o + 1, __float_as_int(m.y));
+                            atomicMax(o + 2, __float_as_int(m.z));
+                            atomicMax(o + 3, __float_as_int(m.w));
                         } else {
                             const int centre = (row0 + (pc0 + p + 1 - G) * 16) / a.ns;
                             if (centre < a.np) *reinterpret_cast<f32x4 *>(outb + (size_t)centre * a.cout_total + ch) = m;

@@ -59,9 +59,74 @@ class ShardedInference:
             if local is None:
                 raise ValueError("ShardedInference needs at least as many clouds as ranks")
             meta[0] = {k: (tuple(v.shape[1:]), v.dtype) for k, v in local.items()}
-        dist.broadcast_object_list(meta, src=0, group=self.group)
+        # `src` is a GLOBAL rank: the group's rank 0 (a sub-group need not contain global rank 0)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast_object_list(meta, src=src, group=self.group)
         out = {}
         for k, (shape, dtype) in meta[0].items():
             t = local[k] if local is not None else torch.empty((0,) + shape, dtype=dtype, device=clouds.device)
             out[k] = all_gather_ragged(t, n, self.group)
         return out
+
+
+# ---------------------------------------------------------------------------------------------- tracking (BASELINE configs[4])
+def sequence_owner(seq, n_sequences, world):
+    """Rank that owns sequence `seq`: the contiguous balanced split of `shard_bounds` (whole sequences per rank)."""
+    for r in range(world):
+        s, e = shard_bounds(n_sequences, r, world)
+        if s <= seq < e:
+            return r
+    raise ValueError(f"sequence {seq} outside 0..{n_sequences - 1}")
+
+
+class ShardedTracking:
+    """Tracking over many sequences on N GPUs (runners/evaluation_tracking.py:262-337 runs ONE sequence per process call;
+    BASELINE configs[4] streams many).  Frames of a sequence are strictly sequential (warm start from the previous frame) and
+    sequences are independent, so the path does not shard below a sequence: every rank owns WHOLE sequences (replicas only, no
+    data-path collective) and drives them in lock-step through one `MultiSequenceTracker`-like object, which lets the frames its
+    sequences are at share every launch.  The only exchange is the final gather of the per-frame results.
+
+    make_tracker(n_local) -> object with .step(frames) -> list (one dict of tensors or None per local sequence), e.g.
+                             `lambda n: MultiSequenceTracker(score_agent, energy_agent, n)`
+    """
+
+    def __init__(self, make_tracker, n_sequences, group=None):
+        self.group, self.n = group, n_sequences
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.lo, self.hi = shard_bounds(n_sequences, self.rank, self.world)
+        self.tracker = make_tracker(self.hi - self.lo) if self.hi > self.lo else None
+
+    def owned(self):
+        return range(self.lo, self.hi)
+
+    def run(self, frame_source, keys=("average_sRT",), gather=True):
+        """frame_source(seq, t) -> (pts [n,1024,3] device, model_names, gt_RT [n,4,4]) or None once sequence `seq` has ended (it is
+        only ever called for sequences this rank owns).  Returns {seq: [per-frame dict of CPU tensors for `keys`]} - for every
+        sequence of the job when `gather` (object all-gather of the final results), else for the local ones."""
+        local = {s: [] for s in self.owned()}
+        t = 0
+        live = set(self.owned())
+        while live:
+            frames = []
+            for s in self.owned():
+                f = frame_source(s, t) if s in live else None
+                if f is None:
+                    live.discard(s)
+                frames.append(f)
+            if not live:
+                break
+            outs = self.tracker.step(frames)
+            for s, o in zip(self.owned(), outs):
+                if o is not None:
+                    local[s].append({k: o[k].detach().cpu() for k in keys})
+            t += 1
+        if not gather or self.world == 1:
+            return local
+        parts = [None] * self.world
+        dist.all_gather_object(parts, local, group=self.group)
+        merged = {}
+        for p in parts:
+            merged.update(p)
+        return merged

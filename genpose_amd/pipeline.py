@@ -82,7 +82,8 @@ class PipelinedPCPredictor:
         return self.smp[j][g]
 
     def run(self, batches, prior_noise=None, noise=None, out=None):
-        """batches: sequence of device tensors [B,1024,3].  prior_noise / noise: optional per-batch explicit draws (tests).
+        """batches: sequence of device tensors [B,1024,3].  prior_noise: optional per-batch STANDARD-NORMAL draws [B*K,9]
+        (scaled by sigma(1) here); noise: optional per-batch (z_langevin, z_predictor) draws (tests).
         Returns a list of pred_pose [B,K,9] float32 tensors (one per batch; written into `out[i]` when given)."""
         results = []
         cur = torch.cuda.current_stream(self.dev)
@@ -202,7 +203,9 @@ class GroupedODEPredictor:
         return self.smp[g]
 
     def run(self, batches, prior_noise=None):
-        """batches: sequence of device tensors [B,1024,3] -> list of pred_pose [B,K,9] float64 (one per batch)."""
+        """batches: sequence of device tensors [B,1024,3] -> list of pred_pose [B,K,9] float64 (one per batch).
+        prior_noise (tests): per-batch STANDARD-NORMAL draws [B*K,9]; scaled by sigma(T0) here, exactly like the PC predictor
+        scales its draws by sigma(1)."""
         self.last_nfev = []
         B1, K, G = self.B1, self.K, self.G
         n = len(batches)
@@ -223,10 +226,10 @@ class GroupedODEPredictor:
                 host = self._prior_host[: g * B1 * K]
                 _randn_1t(host)  # CPU generator, as sde.py:28
                 x0.copy_(host, non_blocking=True)
-                x0.mul_(SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** self.T0)  # prior std at T0
             else:
                 for q in range(g):
                     x0[q * B1 * K:(q + 1) * B1 * K].copy_(prior_noise[i0 + q].reshape(B1 * K, 9))
+            x0.mul_(SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** self.T0)  # prior std at T0 (prior_noise = standard-normal draws, as in the PC predictor)
             smp = self._sampler(g)
             _, x = smp.run(cvec, pts.mean(dim=1), x0, self.T0, num_steps=self.net.cfg.sampling_steps, eps=self.net.sampling_eps)
             self.last_nfev += [int(s["nfev"]) for s in smp.group_stats]

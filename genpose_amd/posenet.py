@@ -107,6 +107,8 @@ class GFObjectPose:
         B = cvec.shape[0]
         R = B * K
         centre = data["pts_center"].float()
+        if self.cfg.posenet_mode == "energy":
+            return self._sample_energy_model(cvec, K, centre, sampler, init_x, T0, noise, return_process)
         if sampler == "pc":
             n = self.cfg.sampling_steps
             if n is None:
@@ -130,6 +132,28 @@ class GFObjectPose:
             return smp.run(cvec, centre, x0, T0, num_steps=self.cfg.sampling_steps, eps=self.sampling_eps, return_process=return_process)
         raise NotImplementedError(sampler)
 
+    def _sample_energy_model(self, cvec, K, centre, sampler, init_x, T0, noise, return_process):
+        """Sampling from the ENERGY model: the score is the autograd gradient of the inner-product energy (posenet.py:94-130
+        with self = PoseEnergyNet, energynet.py:200-222), evaluated by gp_energy_score - never f/sigma.  Secondary path, see
+        genpose_amd/energy_sampling.py."""
+        from . import energy_sampling as es
+        R = cvec.shape[0] * K
+        if sampler == "pc":
+            n = self.cfg.sampling_steps
+            if n is None:
+                raise ValueError("the PC sampler needs cfg.sampling_steps")
+            x0 = self._prior_to_device((R, 9)) if init_x is None else init_x.float()
+            z1, z2 = noise if noise is not None else (None, None)
+            return es.energy_pc_sample(self.pose_score_net, cvec, K, centre, x0, n, z1, z2, eps=self.sampling_eps, return_process=return_process)
+        if sampler == "ode":
+            T0 = self.T if T0 is None else T0
+            pr = self._prior_to_device((R, 9), T=T0)
+            x0 = pr if init_x is None else init_x.float() + pr
+            self.last_energy_ode_stats = {}
+            return es.energy_ode_sample(self.pose_score_net, cvec, K, centre, x0, T0, num_steps=self.cfg.sampling_steps, eps=self.sampling_eps,
+                                        return_process=return_process, stats=self.last_energy_ode_stats)
+        raise NotImplementedError(sampler)
+
     def calc_likelihood(self, data, atol=1e-5, rtol=1e-5):
         """posenet.py:133-147: log-likelihood (bits) of data['sampled_pose'] under the score model, one probe per row drawn from
         the prior.  data['pts_feat'] must be there (mode 'pts_feature')."""
@@ -145,6 +169,17 @@ class GFObjectPose:
                                     stats=self.last_likelihood_stats)
         return ll
 
+    @staticmethod
+    def _uniform_t(t, trusted=False):
+        """The hoisted time embedding serves ONE diffusion time per launch: refuse per-row times instead of silently using row 0
+        (they only occur in training and in get_energy(T=None), which groups the rows by time itself)."""
+        tt = t.reshape(-1)
+        if trusted:
+            return tt[:1].float().contiguous()
+        if tt.numel() > 1 and not bool((tt == tt[0]).all()):
+            raise NotImplementedError("per-row diffusion times: the HIP path evaluates one time value per launch (uniform t)")
+        return tt[:1].float().contiguous()
+
     # ------------------------------------------------------------------ string dispatch (posenet.py:150-179)
     def forward(self, data, mode="score", init_x=None, T0=None):
         if mode == "pts_feature":
@@ -157,14 +192,14 @@ class GFObjectPose:
             if mode == "score" and self.cfg.posenet_mode == "energy":
                 # score of the energy model: gradient of the inner-product energy w.r.t. the pose (energynet.py:200-222)
                 cvec = self.pose_score_net.cloud_embed(data["pts_feat"].float())
-                t0 = data["t"].reshape(-1)[:1].float().contiguous()
+                t0 = self._uniform_t(data["t"], bool(data.get("_t_uniform", False)))
                 tvec = self.pose_score_net.time_embed(t0)
                 sigma = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t0).contiguous()
                 return self.pose_score_net.energy_score(cvec, K, data["sampled_pose"].float().contiguous(), tvec[0], sigma)
             if K == 1:
                 return self.pose_score_net.forward_rows(data["pts_feat"], data["sampled_pose"], data["t"], mode)
             cvec = self.pose_score_net.cloud_embed(data["pts_feat"].float())
-            t0 = data["t"].reshape(-1)[:1].float().contiguous()
+            t0 = self._uniform_t(data["t"], bool(data.get("_t_uniform", False)))
             tvec = self.pose_score_net.time_embed(t0)
             sigma = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t0).contiguous()
             return self.pose_score_net.evaluate(cvec, K, data["sampled_pose"].float().contiguous(), tvec[0], sigma, mode)

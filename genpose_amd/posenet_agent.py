@@ -103,11 +103,19 @@ class PoseNet:
             pts_feat = data["pts_feat"] if not extract_pts_feature else self.net(data, mode="pts_feature")
             self.pts_feature = True
             pose = pose_samples.clone().view(bs * repeat_num, -1).type_as(pts_feat)
-            if T is not None:
-                t = torch.ones(bs * repeat_num, 1).type_as(pts_feat) * T
-            else:
-                # posenet_agent.py:504-509: one random T per cloud -> per-row times, outside the uniform-t hot path
-                raise NotImplementedError("get_energy(T=None) draws a different diffusion time per cloud; pass T (the runners use T=1e-5)")
             pose[:, -3:] -= data["pts_center"].unsqueeze(1).repeat(1, repeat_num, 1).view(bs * repeat_num, -1)
-            energy = self.net({"pts_feat": pts_feat, "sampled_pose": pose, "t": t, "_repeat": repeat_num}, mode="energy")
-            return energy.reshape(bs, repeat_num, -1)
+            rows = {"pts_feat": pts_feat, "sampled_pose": pose, "_repeat": repeat_num, "_t_uniform": True}
+            if T is not None:
+                rows["t"] = torch.ones(bs * repeat_num, 1).type_as(pts_feat) * T
+                return self.net(rows, mode="energy").reshape(bs, repeat_num, -1)
+            # posenet_agent.py:504-509: one random T per cloud from {1e-5, 2e-5, ..., 9e-5} (torch.randint(1, 10)/1e5, drawn on
+            # the CPU generator).  The kernels serve one time value per launch, so the launch is repeated per DISTINCT value (at
+            # most nine) and every cloud keeps the result of its own T.
+            T_samples = torch.randint(int(1e-5 * 1e5), int(1e-4 * 1e5), (bs, 1)).type_as(pts_feat) / 1e5
+            self.last_T_samples = T_samples
+            energy = torch.empty(bs, repeat_num, 2, device=pts_feat.device, dtype=torch.float32)
+            for tv in torch.unique(T_samples.cpu()).tolist():
+                rows["t"] = torch.ones(bs * repeat_num, 1).type_as(pts_feat) * tv
+                e = self.net(rows, mode="energy").reshape(bs, repeat_num, -1)
+                energy = torch.where((T_samples == tv).reshape(bs, 1, 1), e, energy)
+            return energy

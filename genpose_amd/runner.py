@@ -175,9 +175,11 @@ class MultiSequenceTracker:
         for i in (range(len(self.buffers)) if seq is None else [seq]):
             self.buffers[i] = {"model_name": [], "pred_sRT": None}
 
-    def step(self, frames, noise_draws=None, prior_noise=None):
+    def step(self, frames, noise_draws=None, prior=None):
         """frames: one (pts [n_i,1024,3] device, model_names [n_i], gt_RT [n_i,4,4]) per sequence (None = the sequence has no
-        frame this step).  Returns one TrackingRunner-style dict per sequence (None where there was no frame)."""
+        frame this step).  Returns one TrackingRunner-style dict per sequence (None where there was no frame).
+        prior (tests): per sequence, the prior draw [n_i*K,9] exactly as `prior_fn((n_i*K, 9), T=T0)` returns it (already scaled by
+        sigma(T0)) - it stands in for prior_fn, unlike the `prior_noise` of the pipeline predictors (standard-normal draws)."""
         from .samplers import ODESampler
         net = self.score_agent.net
         net._need_weights()
@@ -215,10 +217,10 @@ class MultiSequenceTracker:
         feat = net.pts_encoder(pts)
         cvec = net.pose_score_net.cloud_embed(feat)
         B = pts.shape[0]
-        if prior_noise is None:
+        if prior is None:
             pr = net._prior_to_device((B * K, 9), T=self.T0)
         else:
-            pr = torch.cat([prior_noise[i].reshape(-1, 9) for i in live], dim=0).to(dev).float()
+            pr = torch.cat([prior[i].reshape(-1, 9) for i in live], dim=0).to(dev).float()
         x0 = init_x.unsqueeze(1).repeat(1, K, 1).reshape(B * K, 9).float() + pr
         if B > self.cap_clouds:
             raise ValueError(f"{B} objects in this step exceed the capacity {self.cap_clouds} (n_sequences x max_objects_per_frame)")

@@ -166,7 +166,10 @@ class ODESampler:
         if len(group_clouds) > self.groups or sum(group_clouds) > self.B or (group_clouds and min(group_clouds) <= 0):
             raise ValueError(f"groups {group_clouds} exceed the capacity ({self.groups} groups, {self.B} clouds)")
         blk_h, grp_h = self._tables_host
-        torch.cuda.current_stream(self.dev).synchronize()  # previous launches (and table uploads) have finished
+        # the pinned host tables are rewritten below: only the previous upload out of them has to be complete (the device
+        # tables themselves are overwritten in stream order, behind every launch that still reads them)
+        if getattr(self, "_tables_ev", None) is not None:
+            self._tables_ev.synchronize()
         blk, grp = blk_h.numpy(), grp_h.numpy()
         blk[:] = 0
         grp[:] = 0
@@ -182,6 +185,9 @@ class ODESampler:
             blk[: len(gid)] = np.stack([gid, row0[gid] + local * self.tile, (row0 + rows)[gid]], axis=1)
         self.blk_info.copy_(blk_h, non_blocking=True)
         self.grp_info.copy_(grp_h, non_blocking=True)
+        if getattr(self, "_tables_ev", None) is None:
+            self._tables_ev = torch.cuda.Event()
+        self._tables_ev.record(torch.cuda.current_stream(self.dev))
         self.group_clouds = group_clouds
         return sum(group_clouds)
 
@@ -235,6 +241,10 @@ class ODESampler:
         if self.groups > 1 and return_process and not dense:
             raise NotImplementedError("accepted-state trajectories have a different length per batch: ask for them one batch at a time")
         nb_in = cvec.shape[0]  # ragged mode may use fewer clouds than the capacity
+        expect = sum(self.group_clouds) if self.ragged else self.B
+        if nb_in != expect or init_x.shape[0] != nb_in * self.K:
+            raise ValueError(f"ODE sampler set up for {expect} clouds x {self.K} candidates got {nb_in} clouds / {init_x.shape[0]} rows"
+                             + (" (call set_groups() with this step's grouping first)" if self.ragged else ""))
         self.cvec[:nb_in].copy_(cvec)
         self.centre[:nb_in].copy_(centre)
         self.y[: nb_in * self.K * 9].copy_(init_x.reshape(-1).double())  # init_x f32 -> f64 state (solve_ivp casts y0 to float64)

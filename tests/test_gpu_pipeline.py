@@ -131,13 +131,14 @@ def test_grouped_ode_predictor_equals_agent():
     gen = torch.Generator().manual_seed(4)
     batches = [torch.from_numpy(synth.make_batch(B, start=11 * i)).cuda() for i in range(NB)]
     sig = float(go.ve_sigma(torch.tensor(T0)))
-    priors = [torch.randn(B * K, 9, generator=gen) * sig * (1 + i) for i in range(NB)]
+    draws = [torch.randn(B * K, 9, generator=gen) * (1 + i) for i in range(NB)]  # what the predictor scales by sigma(T0) itself
+    priors = [d * sig for d in draws]
     seq = []
     for i in range(NB):
         agent.net.prior_fn = lambda shape, T=1.0, i=i: priors[i]
         seq.append(agent.pred_func({"pts": batches[i], "pts_center": batches[i].mean(dim=1)}, K, save_path=None, T0=T0).clone())
     pred = GroupedODEPredictor(agent, B, K, T0=T0, batches_per_launch=2)
-    got = pred.run(batches, prior_noise=priors)
+    got = pred.run(batches, prior_noise=draws)
     torch.cuda.synchronize()
     assert len(got) == NB and len(pred.last_nfev) == NB
     for i in range(NB):
@@ -186,7 +187,7 @@ def test_multi_sequence_tracker_equals_per_sequence_runs():
         frames = [(seqs[s_]["pts"][f], seqs[s_]["names"], seqs[s_]["gt"]) for s_ in range(len(counts))]
         if f == 1:
             frames[2] = None  # a sequence may skip a step; its warm start must survive
-        got = multi.step(frames, noise_draws=draws[f], prior_noise=priors[f])
+        got = multi.step(frames, noise_draws=draws[f], prior=priors[f])
         torch.cuda.synchronize()
         for s_ in range(len(counts)):
             if frames[s_] is None:
@@ -230,7 +231,7 @@ def test_multi_sequence_tracker_changing_object_counts():
             frames.append((pts, [f"s{s_}o{j}" for j in range(c)], gt))
             draws.append([torch.randn(c, generator=gen), torch.randn(c, 4, generator=gen), torch.randn(c, generator=gen), torch.randn(c, 3, generator=gen)])
             priors.append(torch.randn(c * K, 9, generator=gen) * sig)
-        got = multi.step(frames, noise_draws=draws, prior_noise=priors)
+        got = multi.step(frames, noise_draws=draws, prior=priors)
         torch.cuda.synchronize()
         assert smp_id in (None, id(multi._sampler))  # one solver for every grouping
         smp_id = id(multi._sampler)
