@@ -11,7 +11,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-SO = os.path.join(LIBDIR, "libgenpose_hip.so")
+# GP_BUILD_TAG=<tag> (tuning): build a variant beside the shipped library (lib/libgenpose_hip_<tag>.so, objects in lib/obj_<tag>/);
+# select it at run time with GENPOSE_HIP_LIB=<path>
+TAG = os.environ.get("GP_BUILD_TAG", "")
+SO = os.path.join(LIBDIR, f"libgenpose_hip_{TAG}.so" if TAG else "libgenpose_hip.so")
+OBJDIR = os.path.join(LIBDIR, f"obj_{TAG}") if TAG else LIBDIR
 SOURCES = ["misc.hip", "pn2_ops.hip", "sa_mlp.hip", "scorenet.hip", "rk45.hip", "rank.hip", "preprocess.hip", "score_div.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
 TIMING = bool(os.environ.get("GP_TIMING"))  # tuning build: phase timestamps (needs relocatable device code)
@@ -34,7 +38,7 @@ def _deps():
 
 
 def build(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     newest = max(os.path.getmtime(p) for p in _deps())
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
@@ -42,7 +46,7 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     for s in srcs:
-        o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
+        o = os.path.join(OBJDIR, os.path.basename(s) + ".o")
         objs.append(o)
         cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
         if verbose:

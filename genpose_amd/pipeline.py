@@ -235,3 +235,79 @@ class GroupedODEPredictor:
             self.last_nfev += [int(s["nfev"]) for s in smp.group_stats]
             out[i0:i0 + g].copy_(x.reshape(g, B1, K, 9))
         return [out[i] for i in range(n)]
+
+
+class FullPipelinePredictor:
+    """BASELINE configs[2]: score model (encoder -> PC sampler) + energy model (encoder -> energy of every candidate) -> ranking ->
+    top-`ratio` aggregation for one batch of B clouds - what `pred_func` -> `get_energy` -> `rank_aggregate` return when called one
+    after the other (asserted in tests/test_gpu_fullsize.py), restructured around the one dependency that matters: the ENERGY
+    encoder needs only the clouds, not the candidates.  It runs on a second HIP stream underneath the score model's sampler
+    (whose step launches leave part of the chip idle: 12 800 rows = 400 32-row tiles = 1.56 rounds of the 256 CUs), and joins
+    before the energy evaluation.
+
+    score_agent / energy_agent : genpose_amd.posenet_agent.PoseNet with weights loaded (sampler_mode ['pc'] on the score agent)
+    """
+
+    def __init__(self, score_agent, energy_agent, B, K, num_steps, ratio=0.6, T_energy=1e-5, overlap=True):
+        _lib.check_device()
+        self.snet, self.enet = score_agent.net, energy_agent.net
+        self.snet._need_weights()
+        self.enet._need_weights()
+        if self.enet.cfg.posenet_mode != "energy" or self.snet.cfg.posenet_mode != "score":
+            raise ValueError("FullPipelinePredictor(score_agent, energy_agent): agents in the wrong order / mode")
+        self.B, self.K, self.n, self.ratio = B, K, num_steps, ratio
+        self.dev = self.snet.device
+        self.overlap = overlap
+        self.side = torch.cuda.Stream(self.dev, priority=0) if overlap else None
+        self.smp = PCSampler(self.snet.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False)
+        self.prior_host = torch.empty(B * K, 9).pin_memory()
+        self.x0 = torch.empty(B * K, 9, device=self.dev)
+        self.ev_h2d = torch.cuda.Event()
+        self.ev_h2d.record()
+        self.ev_side = torch.cuda.Event()
+        t = torch.full((1,), float(T_energy), device=self.dev)
+        self.tvec_e = self.enet.pose_score_net.time_embed(t)[0].contiguous()
+        self.sigma_e = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t).contiguous()
+        self.pose_e = torch.empty(B * K, 9, device=self.dev)
+
+    def run(self, pts, prior_noise=None, noise=None):
+        """pts [B,1024,3] device tensor -> dict(pred_pose [B,K,9] f32, energy [B,K,2], sorted_poses, sorted_energy, order, avg_pose [B,7]).
+        prior_noise (tests): standard-normal draws [B*K,9]; noise (tests): (z_langevin, z_predictor) [n,B*K,9]."""
+        from . import reward
+        B, K = self.B, self.K
+        if pts.shape[0] != B:
+            raise ValueError(f"predictor built for {B} clouds got {pts.shape[0]}")
+        cur = torch.cuda.current_stream(self.dev)
+        centre = pts.mean(dim=1)
+        # ---- energy model's encoder + per-cloud embedding: depends on the clouds only -> side stream
+        if self.side is not None:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                cvec_e = self.enet.pose_score_net.cloud_embed(self.enet.pts_encoder(pts))
+                self.ev_side.record(self.side)
+            cvec_e.record_stream(cur)
+        # ---- score model: encoder -> embedding -> prior -> the whole T-step loop as one graph replay
+        cvec = self.snet.pose_score_net.cloud_embed(self.snet.pts_encoder(pts))
+        if prior_noise is None:
+            self.ev_h2d.synchronize()
+            _randn_1t(self.prior_host)  # CPU generator, as sde.py:28
+            self.x0.copy_(self.prior_host, non_blocking=True)
+            self.ev_h2d.record(cur)
+        else:
+            self.x0.copy_(prior_noise.reshape(B * K, 9))
+        self.x0.mul_(SIGMA_MAX)
+        z1, z2 = noise if noise is not None else (None, None)
+        _, mean_x = self.smp.run(cvec, centre, self.x0, z1, z2)
+        pred = mean_x.reshape(B, K, 9).clone()
+        # ---- energy of every candidate (posenet_agent.py:471-527: translations relative to the cloud centre), ranking, aggregation
+        if self.side is not None:
+            cur.wait_event(self.ev_side)
+        else:
+            cvec_e = self.enet.pose_score_net.cloud_embed(self.enet.pts_encoder(pts))
+        pose = self.pose_e.view(B, K, 9)
+        pose.copy_(pred)
+        pose[:, :, 6:] -= centre.unsqueeze(1)
+        energy = self.enet.pose_score_net.evaluate(cvec_e, K, self.pose_e, self.tvec_e, self.sigma_e, "energy").reshape(B, K, 2)
+        out = reward.rank_aggregate(pred, energy, ratio=self.ratio)
+        out["pred_pose"], out["energy"] = pred, energy
+        return out

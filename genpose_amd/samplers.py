@@ -50,13 +50,15 @@ class PCSampler:
         self.use_graph = use_graph
         self.graph = None
 
+    def launch_step(self, i):
+        """Launch i of the chain (0 <= i <= n) on the current stream: finishes step i-1 and, for i < n, evaluates the score at t_i."""
+        _lib.call("gp_pc_step_grouped", self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
+                  ptr(self.sched), ptr(self.z1), ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
+                  ptr(self.traj), stream_ptr())
+
     def _launch_all(self):
-        st = stream_ptr()
-        w = self.net.w.ref()
         for i in range(self.n + 1):
-            _lib.call("gp_pc_step_grouped", self.groups, self.B // self.groups, self.K, i, self.n, w, ptr(self.cvec), ptr(self.tvec_all), ptr(self.sched), ptr(self.z1),
-                      ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
-                      ptr(self.traj), st)
+            self.launch_step(i)
 
     def run(self, cvec, centre, init_x, z_langevin=None, z_predictor=None, slot_free_event=None, graph_events=None):
         """cvec [B,768], centre [B,3], init_x [R,9]; noise [n,R,9] (drawn on the device generator if None).

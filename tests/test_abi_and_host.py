@@ -235,3 +235,26 @@ def test_product_never_imports_the_oracle():
         for k in [k for k in sys.modules if k == "genpose_amd" or k.startswith("genpose_amd.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_bench_spawns_the_documented_launch_line(monkeypatch):
+    """`python bench.py --gpus N` with no launcher environment re-executes itself under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import argparse
+    import subprocess
+    import sys as _sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert bench.self_launch(argparse.Namespace(gpus=8)) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["GP_BENCH_LAUNCH"] == "self" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

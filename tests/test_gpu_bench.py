@@ -1,0 +1,49 @@
+"""bench.py launch mechanics on the GPU box: `python bench.py --gpus N` must run without an external launcher (it spawns
+`python -m torch.distributed.run` itself), rank 0 prints exactly one JSON line, and the N-rank path is exercised on ONE device
+(GP_BENCH_ONE_DEVICE=1: every rank uses cuda:0, collectives on gloo) so a 1-GPU box covers it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "8", "--cand", "10", "--sde-steps", "6", "--batches-per-launch", "1",
+         "--no-cpu-baseline", "--no-secondary"]
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "cpu_baseline", "timing", "launch"}
+
+
+def _run(extra, env_extra=None):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_self_launched_on_one_device():
+    line = _run(["--gpus", "2"], {"GP_BENCH_ONE_DEVICE": "1"})
+    assert REQUIRED <= set(line)
+    assert line["n_gpus"] == 2 and line["launch"] == {"mode": "self", "world_size_observed": 2, "backend": "gloo"}
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["clouds_per_gpu"] == 8 and line["config"]["parallelism"] == "clouds sharded x2"
+    assert abs(line["value"] - 2 * 8 * 2 / (line["ms_per_step"] * 2e-3)) <= 0.01 * line["value"]  # whole-job aggregate over both ranks
+
+
+def test_one_rank_direct_and_through_the_launcher_agree():
+    direct = _run(["--gpus", "1"])
+    spawned = _run(["--gpus", "1"], {"GP_BENCH_FORCE_LAUNCH": "1"})
+    assert direct["launch"]["mode"] == "direct" and spawned["launch"]["mode"] == "self"
+    assert set(direct) == set(spawned) and REQUIRED <= set(direct)
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data", "config", "higher_is_better"):
+        assert direct[k] == spawned[k], k
+    assert direct["roofline"]["kernel"] == spawned["roofline"]["kernel"]
+    assert direct["roofline"]["flops_per_launch"] == spawned["roofline"]["flops_per_launch"]
