@@ -229,11 +229,20 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         if (h < 2) mfma_preload<NV>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
         mfma_run<NV, PT>(stH[h & 1], H2, L::LDH, 0, net.w_headx, HID / 16, HEADS / 16, nch[h], acc);
         GP_T(7 + 3 * h);
-        HeadOps<PT, NV> o;
-        head_ops_load<P, PT, NV>(o, lds, pre.staged, cvec, tvec, h, nch[h], cloud, pre.cloud0);
         float part[PT][3];  // [p-chunk][component], this wave's n-chunks of head h
 #pragma unroll
         for (int p = 0; p < PT; ++p) part[p][0] = part[p][1] = part[p][2] = 0.f;
+#ifdef GP_ABL_NOEPI  // ablation build (tuning): the accumulators are consumed, the epilogue arithmetic is not done
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                asm volatile("" ::"v"(acc[i][p]));
+                part[p][i % 3] = acc[i][p].x;
+            }
+#else
+        HeadOps<PT, NV> o;
+        head_ops_load<P, PT, NV>(o, lds, pre.staged, cvec, tvec, h, nch[h], cloud, pre.cloud0);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
 #pragma unroll
@@ -249,6 +258,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
                 part[p][2] += v.x * o.w2[i].x + v.y * o.w2[i].y + v.z * o.w2[i].z + v.w * o.w2[i].w;
             }
         }
+#endif
         // every lane parks its partial sums; the 4 channel groups x 4 waves are combined below in a fixed order
 #pragma unroll
         for (int p = 0; p < PT; ++p)

@@ -136,6 +136,13 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_gn;
     const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
+    // GP_ABL_*: ablation builds (tuning; scratch/r2_call4.sh, profiles/r2_sampler_ablation.txt) - what each phase of a launch costs
+#ifdef GP_ABL_EMPTY  // the launch itself
+    return;
+#endif
+#ifdef GP_ABL_NOPRO
+    if (i == a.nsteps) return;
+#endif
     TrunkPre<P> pre;
     GP_WG_BEGIN();
     GP_T(0);
@@ -145,7 +152,11 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         sigma = a.sched[(size_t)i * 4 + 0];  // requested now, used after the trunk
         gp_pin(sigma);
     }
+#ifdef GP_ABL_NOPRO  // no operand loads / batch-mean reduction / PC update
+    if (false) {
+#else
     if (i > 0) {
+#endif
         // (1) row threads request their operands first; (2) meanwhile the last wave reduces the per-block partial sums
         // of step i-1 into the batch-mean gradient norm (fixed order: deterministic); (3) one barrier, then the update.
         const bool live = row0 + tid < a.nrows;
@@ -231,6 +242,9 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     GP_T(1);
     trunk_ftheta<P>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre);
     GP_T(16);
+#ifdef GP_ABL_NOTAIL  // no score write / norm partial
+    if (sigma != 12345.f) return;
+#endif
     float *F = lds + L::OFF_H1;
     for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
         const int r = e / POSE, j = e - r * POSE;
