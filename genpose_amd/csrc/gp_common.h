@@ -294,12 +294,19 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// max over the 16 lanes that share (lane >> 4): the 16 points of one p-chunk
+// max over the 16 lanes that share (lane >> 4): the 16 points of one p-chunk.  DPP row operations (VALU, no LDS traffic: the
+// ds_bpermute form of __shfl_xor costs an LDS instruction per step, and the SA epilogues take 64 of these per 16 rows); after
+// row_mirror every lane of the row holds the row's maximum.  max is order-independent: same bits as any other reduction order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_max_f32(float v) {
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+    return fmaxf(v, o);
+}
 __device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64));
-    v = fmaxf(v, __shfl_xor(v, 2, 64));
-    v = fmaxf(v, __shfl_xor(v, 4, 64));
-    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = dpp_max_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_max_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_max_f32<0x141>(v);  // row_half_mirror
+    v = dpp_max_f32<0x140>(v);  // row_mirror
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {

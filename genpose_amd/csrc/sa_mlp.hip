@@ -164,23 +164,27 @@ __global__ __launch_bounds__(256) void point_linear_kernel(int M, int K, int N, 
     if (Kp > K)
         for (int e = tid; e < P * (Kp - K); e += 256) lds[(e / (Kp - K)) * ld + K + e % (Kp - K)] = 0.f;
     __syncthreads();
-    // each wave owns 16 rows and sweeps all channel chunks
+    // every wave takes all 64 rows and every fourth channel chunk: a weight fragment feeds four MFMAs (with 16 rows per wave and
+    // all chunks it fed one, and every wave streamed the whole weight set: the weight-stream-bound regime of DESIGN.md §4.2)
     const int KG = Kp / 16, NC = gp_round16(N) / 16;
-    for (int ncb = 0; ncb < NC; ncb += 4) {
+    for (int ncb = wave; ncb < NC; ncb += 16) {
         int nc[4], nv = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            nc[i] = ncb + i;
+            nc[i] = ncb + 4 * i;
             nv += nc[i] < NC;
         }
-        f32x4 acc[4][1];
-        mfma_tile_n<1>(nv, lds, ld, wave, Wp, KG, NC, nc, acc);
-        const int row = row0 + wave * 16 + (lane & 15);
+        f32x4 acc[4][4];
+        mfma_tile_n<4>(nv, lds, ld, 0, Wp, KG, NC, nc, acc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i >= nv) break;
             const int ch = nc[i] * 16 + 4 * (lane >> 4);
-            if (row < M && ch < N) *reinterpret_cast<f32x4 *>(Z + (size_t)row * N + ch) = acc[i][0];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = row0 + p * 16 + (lane & 15);
+                if (row < M && ch < N) *reinterpret_cast<f32x4 *>(Z + (size_t)row * N + ch) = acc[i][p];
+            }
         }
     }
 }
@@ -647,6 +651,9 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
     load_ops(0, jn, dcur, zcur);
     jn = load_idx(1);
     int gstep = 0;  // global ring step: slice gstep % Q2 sits in slot gstep % 3
+    f32x4 wpre[4];  // first fragment group of the upcoming ring step
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wpre[u] = ring[u * 64 + lane];
 #pragma unroll 1
     for (int it = 0; it < nits_wg; ++it) {
         int lo = lane;
@@ -689,7 +696,9 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
                     h2[n0 + u] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
                 }
         }
-        // ---- layer 3 through the ring: Q2 steps, all Q3 output chunks accumulate across the steps
+        // ---- layer 3 through the ring: Q2 steps, all Q3 output chunks accumulate across the steps.
+        // Fragment groups are requested one group ahead; the first group of the NEXT step is requested before this step's barrier
+        // (its slice was written two steps ago and published by the previous barrier), so no step starts on an LDS round trip.
         f32x4 acc3[Q3];
 #pragma unroll
         for (int n = 0; n < Q3; ++n) acc3[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -704,16 +713,20 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
 #pragma unroll
                 for (int u = 0; u < PER_T; ++u) hold[u] = src[tid + u * NTH];
             }
-            const f32x4 *slot = ring + (gstep % 3) * SLICE;
+            const f32x4 *slot = ring + (gstep % 3) * SLICE, *nslot = ring + ((gstep + 1) % 3) * SLICE;
 #pragma unroll
             for (int n0 = 0; n0 < Q3; n0 += 4) {
-                f32x4 wf[4];
+                f32x4 wf[4], wn[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) wf[u] = slot[(n0 + u) * 64 + lo];
+                for (int u = 0; u < 4; ++u) wf[u] = wpre[u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wn[u] = (n0 + 4 < Q3) ? slot[(n0 + 4 + u) * 64 + lo] : nslot[u * 64 + lo];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc3[n0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h2[q][jj], acc3[n0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wpre[u] = wn[u];
             }
             ++gstep;
             __syncthreads();

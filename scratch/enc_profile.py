@@ -1,5 +1,5 @@
 """Encoder alone (tuning): python scratch/enc_profile.py B [iters] - HIP-event time per pass; run under rocprofv3 --kernel-trace --stats for the per-kernel table."""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from genpose_amd import synth
 from genpose_amd.encoder import Pointnet2EncoderHIP

@@ -1,5 +1,5 @@
 """Sampler launch chain alone (tuning): python scratch/pc_time.py B [B ...] - HIP-event time per pc_step launch (graph replay)."""
-import os, sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from genpose_amd.scorenet import ScoreNetHIP
 from genpose_amd.samplers import PCSampler
