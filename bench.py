@@ -146,7 +146,7 @@ def main():
         pred = score_agent.pred_func(data, repeat_num=K, save_path=None, T0=T0)
         out = pred
         if energy_agent is not None:
-            energy = energy_agent.get_energy(data={"pts": pts, "pts_center": centre}, pose_samples=pred, T=1e-5)
+            energy = energy_agent.get_energy(data=data, pose_samples=pred, T=1e-5)  # same dict: the grouping ticket is taken over
             out = reward.rank_aggregate(pred, energy, ratio=0.6)["avg_pose"]
         gather(out)
         return out

@@ -80,7 +80,55 @@ class Pointnet2EncoderHIP:
                 cur = ws["new_xyz"][l]
         return xyz0
 
-    def forward(self, pts, return_intermediates=False, slot=0, centres_done=False):
+    def _ball_queries(self, ws, xyz0, B, N):
+        """Ball queries of every grouping level (they depend on the coordinates only) into ws['bq']."""
+        st = stream_ptr()
+        cfg = self.cfg
+        xyz, n = xyz0, N
+        for k, npnt in enumerate(cfg["npoints"]):
+            if npnt is None:
+                break
+            new_xyz = ws["new_xyz"][k]
+            radii, nss = cfg["radii"][k], cfg["nsamples"][k]
+            if len(self.w.levels[k]) == 2:
+                _lib.call("gp_ball_query_msg", B, n, npnt, float(radii[0]), nss[0], float(radii[1]), nss[1], ptr(new_xyz), ptr(xyz),
+                          ptr(ws["bq"][k][0]), ptr(ws["bq"][k][1]), st)
+            else:
+                for i in range(len(self.w.levels[k])):
+                    ws["bq"][k][i].zero_()
+                    _lib.call("gp_ball_query", B, n, npnt, float(radii[i]), nss[i], ptr(new_xyz), ptr(xyz), ptr(ws["bq"][k][i]), st)
+            xyz, n = new_xyz, npnt
+
+    def grouping_key(self):
+        """Everything the sampled centres and neighbourhoods depend on besides the coordinates."""
+        c = self.cfg
+        return (tuple(c["npoints"]), tuple(map(tuple, c["radii"])), tuple(map(tuple, c["nsamples"])))
+
+    def prepare_grouping(self, pts, slot=0):
+        """Furthest point sampling + gather + ball queries for every level into workspace `slot`; returns that workspace.  These
+        depend on the point coordinates only - not on any weight - so a second encoder with the same grouping configuration (the
+        energy model's, which sees the same clouds) can take them over: forward(pts, grouping=<this workspace>)."""
+        xyz0 = self.sample_centres(pts, slot)
+        B, N, _ = xyz0.shape
+        ws = self._workspace(B, N, slot)
+        self._ball_queries(ws, xyz0, B, N)
+        ws["_grouping_key"] = self.grouping_key()
+        ws["_gen"] = ws.get("_gen", 0) + 1
+        return ws
+
+    def grouping_ticket(self, pts, ws):
+        """What a second encoder needs to take this grouping over safely (GFObjectPose.extract_pts_feature): which clouds it belongs
+        to and which generation of the workspace it is (the workspace is overwritten by the next call)."""
+        return {"ws": ws, "gen": ws["_gen"], "key": self.grouping_key(), "ptr": pts.data_ptr(), "shape": tuple(pts.shape)}
+
+    @staticmethod
+    def ticket_valid(ticket, pts, key):
+        return (ticket is not None and ticket["key"] == key and ticket["ptr"] == pts.data_ptr() and ticket["shape"] == tuple(pts.shape)
+                and ticket["ws"].get("_gen") == ticket["gen"])
+
+    def forward(self, pts, return_intermediates=False, slot=0, centres_done=False, grouping=None):
+        """grouping: workspace returned by prepare_grouping() of an encoder with the same grouping configuration, for the SAME
+        clouds: its centres and neighbourhood indices are used instead of being recomputed."""
         _lib.check_device()
         if not pts.is_cuda or pts.dtype != torch.float32:
             raise RuntimeError("pts must be a float32 CUDA tensor")
@@ -90,9 +138,16 @@ class Pointnet2EncoderHIP:
         st = stream_ptr()
         cfg = self.cfg
         group_levels = [k for k, npnt in enumerate(cfg["npoints"]) if npnt is not None]
-        # ---- furthest point sampling + gather for every level
-        if not centres_done:
-            self.sample_centres(pts, slot)
+        if grouping is not None:
+            if grouping.get("_grouping_key") != self.grouping_key() or grouping["new_xyz"][0].shape[0] != B:
+                raise ValueError("grouping comes from an encoder with a different configuration / batch")
+            src = grouping
+        else:
+            src = ws
+            # ---- furthest point sampling + gather for every level
+            if not centres_done:
+                self.sample_centres(pts, slot)
+            self._ball_queries(ws, xyz0, B, N)
         # ---- set abstraction levels
         xyz, feats, n, cin = xyz0, None, N, 0
         for k, npnt in enumerate(cfg["npoints"]):
@@ -116,15 +171,8 @@ class Pointnet2EncoderHIP:
                     zoff += sc.couts[0]
                 feats, n, cin = out, 1, cout_total
                 break
-            new_xyz = ws["new_xyz"][k]
-            radii, nss = cfg["radii"][k], cfg["nsamples"][k]
-            if len(scales) == 2:
-                _lib.call("gp_ball_query_msg", B, n, npnt, float(radii[0]), nss[0], float(radii[1]), nss[1], ptr(new_xyz), ptr(xyz),
-                          ptr(ws["bq"][k][0]), ptr(ws["bq"][k][1]), st)
-            else:
-                for i in range(len(scales)):
-                    ws["bq"][k][i].zero_()
-                    _lib.call("gp_ball_query", B, n, npnt, float(radii[i]), nss[i], ptr(new_xyz), ptr(xyz), ptr(ws["bq"][k][i]), st)
+            new_xyz = src["new_xyz"][k]
+            nss = cfg["nsamples"][k]
             # first layer hoisted: feature half once per source point, xyz half while gathering (csrc/sa_mlp.hip)
             z = ws["z"][k]
             zstride = sum(sc.couts[0] for sc in scales)
@@ -134,13 +182,15 @@ class Pointnet2EncoderHIP:
             for i, sc in enumerate(scales):
                 (w1, b1), (w2, b2), (w3, b3) = sc.layers
                 _lib.call("gp_sa_pre_mlp_max", B, n, npnt, nss[i], sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(new_xyz),
-                          ptr(ws["bq"][k][i]), ptr(z), zstride, zoff, ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out),
+                          ptr(src["bq"][k][i]), ptr(z), zstride, zoff, ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out),
                           cout_total, off, st)
                 off += sc.couts[2]
                 zoff += sc.couts[0]
             xyz, feats, n, cin = new_xyz, out, npnt, cout_total
         res = feats.reshape(B, -1).clone()
         if return_intermediates:
+            if src is not ws:
+                ws = dict(ws, new_xyz=src["new_xyz"], fps_idx=src["fps_idx"], bq=src["bq"])
             return res, ws
         return res
 

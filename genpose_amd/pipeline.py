@@ -258,6 +258,7 @@ class FullPipelinePredictor:
         self.B, self.K, self.n, self.ratio = B, K, num_steps, ratio
         self.dev = self.snet.device
         self.overlap = overlap
+        self.share_grouping = self.snet.pts_encoder.grouping_key() == self.enet.pts_encoder.grouping_key()
         self.side = torch.cuda.Stream(self.dev, priority=0) if overlap else None
         self.smp = PCSampler(self.snet.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False)
         self.prior_host = torch.empty(B * K, 9).pin_memory()
@@ -279,15 +280,19 @@ class FullPipelinePredictor:
             raise ValueError(f"predictor built for {B} clouds got {pts.shape[0]}")
         cur = torch.cuda.current_stream(self.dev)
         centre = pts.mean(dim=1)
+        # ---- centres and neighbourhoods (furthest point sampling, ball queries) depend on the coordinates only: computed ONCE and
+        # used by both encoders (the reference computes them twice, once per agent)
+        enc_s, enc_e = self.snet.pts_encoder, self.enet.pts_encoder
+        grouping = enc_s.prepare_grouping(pts) if self.share_grouping else None
         # ---- energy model's encoder + per-cloud embedding: depends on the clouds only -> side stream
         if self.side is not None:
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                cvec_e = self.enet.pose_score_net.cloud_embed(self.enet.pts_encoder(pts))
+                cvec_e = self.enet.pose_score_net.cloud_embed(enc_e.forward(pts, grouping=grouping))
                 self.ev_side.record(self.side)
             cvec_e.record_stream(cur)
         # ---- score model: encoder -> embedding -> prior -> the whole T-step loop as one graph replay
-        cvec = self.snet.pose_score_net.cloud_embed(self.snet.pts_encoder(pts))
+        cvec = self.snet.pose_score_net.cloud_embed(enc_s.forward(pts, grouping=grouping))
         if prior_noise is None:
             self.ev_h2d.synchronize()
             _randn_1t(self.prior_host)  # CPU generator, as sde.py:28
@@ -303,7 +308,7 @@ class FullPipelinePredictor:
         if self.side is not None:
             cur.wait_event(self.ev_side)
         else:
-            cvec_e = self.enet.pose_score_net.cloud_embed(self.enet.pts_encoder(pts))
+            cvec_e = self.enet.pose_score_net.cloud_embed(enc_e.forward(pts, grouping=grouping))
         pose = self.pose_e.view(B, K, 9)
         pose.copy_(pred)
         pose[:, :, 6:] -= centre.unsqueeze(1)

@@ -61,8 +61,16 @@ class GFObjectPose:
 
     # ------------------------------------------------------------------ pieces
     def extract_pts_feature(self, data):
+        """posenet.py:71-91.  The sampled centres and ball-query neighbourhoods depend on the coordinates only, so the SCORE agent
+        leaves a ticket for them in the dict (`_grouping`) and the ENERGY agent, called next with the same dict and the same clouds
+        (evaluation_single.py:339-343, evaluation_tracking.py:316-321), takes them over instead of recomputing them."""
         self._need_weights()
-        return self.pts_encoder(data["pts"])
+        enc, pts = self.pts_encoder, data["pts"]
+        if self.cfg.posenet_mode == "energy" and enc.ticket_valid(data.get("_grouping"), pts, enc.grouping_key()):
+            return enc.forward(pts, grouping=data["_grouping"]["ws"])
+        ws = enc.prepare_grouping(pts)
+        data["_grouping"] = enc.grouping_ticket(pts, ws)
+        return enc.forward(pts, grouping=ws)
 
     def _rows(self, data):
         """-> (cvec [B,768], K, centre [B,3] or None)"""

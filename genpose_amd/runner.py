@@ -214,7 +214,8 @@ class MultiSequenceTracker:
         init_x = init_sRT[:, :3, [0, 1, 3]].permute(0, 2, 1).reshape(B0 := init_sRT.shape[0], -1).clone()
         init_x[:, -3:] -= centre
         # ---- score model: encoder -> warm-started ODE, one group per sequence
-        feat = net.pts_encoder(pts)
+        shared = {"pts": pts, "pts_center": centre}
+        feat = net.extract_pts_feature(shared)  # leaves the grouping ticket for the energy agent
         cvec = net.pose_score_net.cloud_embed(feat)
         B = pts.shape[0]
         if prior is None:
@@ -232,7 +233,7 @@ class MultiSequenceTracker:
         _, x = smp.run(cvec, centre, x0, self.T0, num_steps=net.cfg.sampling_steps, eps=net.sampling_eps)
         pred = x.reshape(B, K, 9)
         # ---- energy model + ranking + aggregation for all clouds at once (row / cloud local)
-        energy = self.energy_agent.get_energy(data={"pts": pts, "pts_center": centre}, pose_samples=pred, T=1e-5)
+        energy = self.energy_agent.get_energy(data=shared, pose_samples=pred, T=1e-5)
         sel = max(1, int(self.ratio * K))
         r = reward.rank_aggregate(pred, energy, selected_num=sel)
         average_sRT = rotation.quat_trans_to_RT(r["avg_pose"])
