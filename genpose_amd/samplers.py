@@ -116,6 +116,7 @@ class ODESampler:
     scipy's adaptive controller, rtol = atol = 1e-5, batch-global RMS error norm)."""
 
     TRAJ_CAP = 192
+    CHUNKS = (8, 12, 16, 24, 32, 40, 48, 64, 80, 96, 128)  # attempts per first replay
 
     def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: every batch keeps its own adaptive
@@ -156,9 +157,8 @@ class ODESampler:
         self.centre = torch.empty(B, 3, device=self.dev)
         self.traj = None
         self.use_graph, self.poll = use_graph, poll
-        self.graph = None
-        self.graph_traj = None
-        self.graph_dense = None
+        self._graphs = {}        # kind ('graph' | 'graph_traj' | 'graph_dense') -> {attempts per replay: captured graph}
+        self._attempt_hist = {}  # (kind, T0) -> attempts the previous solve took
         self.last_stats = {}
 
     def set_groups(self, group_clouds):
@@ -259,7 +259,7 @@ class ODESampler:
             if getattr(self, "_dense_key", None) != key:
                 self._dense_traj = torch.zeros(num_steps, self.R * 9, dtype=torch.float64, device=self.dev)
                 self._dense_key = key
-                self.graph_dense = None  # the captured attempt holds the trajectory pointer
+                self._graphs.pop("graph_dense", None)  # the captured attempts hold the trajectory pointer
             self._t_eval = torch.from_numpy(np.linspace(T0, eps, num_steps)).to(self.dev)
             traj = self._dense_traj
             self._phase(0, None, t0=T0, t_bound=eps, rtol=rtol, atol=atol)
@@ -277,22 +277,32 @@ class ODESampler:
         self._embed()
         self._phase(2, traj)
         n_done = 0
+        # The attempt count is data dependent (scipy's controller), but it barely moves between solves of the same kind (same T0, same
+        # kind of clouds), and an attempt launched on a FINISHED solve exits at once.  So the first replay is a graph sized for the
+        # previous solve's attempt count (+ margin): in the common case the whole adaptive loop is ONE graph replay and one status
+        # read; a solve that needs more continues in chunks of `poll` attempts.
+        gname = "graph_dense" if dense else ("graph_traj" if traj is not None else "graph")
+        hist_key = (gname, round(float(T0), 3))
+        expect = self._attempt_hist.get(hist_key)
+        first = self.poll if expect is None else next((c for c in self.CHUNKS if c >= expect + 2), self.CHUNKS[-1])
         while True:
+            chunk = first if n_done == 0 else self.poll
             if self.use_graph:
-                gname = "graph_dense" if dense else ("graph_traj" if traj is not None else "graph")
-                if getattr(self, gname) is None:
-                    self._attempt(traj)  # warm-up outside capture
-                    n_done += 1
+                graphs = self._graphs.setdefault(gname, {})
+                if chunk not in graphs:
+                    if not graphs:
+                        self._attempt(traj)  # warm-up outside capture
+                        n_done += 1
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        for _ in range(self.poll):
+                        for _ in range(chunk):
                             self._attempt(traj)
-                    setattr(self, gname, g)
-                getattr(self, gname).replay()
+                    graphs[chunk] = g
+                graphs[chunk].replay()
             else:
-                for _ in range(self.poll):
+                for _ in range(chunk):
                     self._attempt(traj)
-            n_done += self.poll
+            n_done += chunk
             sts = self._read_states()
             if self.ragged:
                 sts = sts[: len(self.group_clouds)]
@@ -304,6 +314,8 @@ class ODESampler:
             raise RuntimeError("ODE sampler: required step size is less than spacing between numbers (scipy TOO_SMALL_STEP)")
         st = sts[0]
         self.group_stats = sts
+        self._attempt_hist[hist_key] = max(int(s_["n_attempts"]) for s_ in sts)
+        self.last_replays = {"first_chunk": first, "attempts_launched": n_done}
         self._phase(4, traj, t0=eps)
         self._embed()
         nstates = (num_steps if dense else int(st["n_accepted"]) + 1) if traj is not None else 0

@@ -17,6 +17,8 @@ What each file pins:
   g7_pc.npz       PoseNet.pred_func with the PC sampler, 20 steps, logged randn_like draws.
   g8_rank.npz     get_energy + sort_poses_by_energy + sort_sRT_by_energy(ratio=.6,'average').
   g9_track.npz    3-frame tracking loop semantics (evaluation_tracking.py:262-337) incl. add_noise_to_RT draws.
+  g10..g13        mAP evaluation, depth -> cloud pre-processing, likelihood, score of the energy model (--g10 .. --g13).
+  g14_train_step.npz  one training step of the score model (--g14): loss, clipped gradients, Adam update, EMA, BN statistics.
 """
 import hashlib
 import os
@@ -390,7 +392,72 @@ def main_g13():
     print("g13_energy_score.npz", os.path.getsize(os.path.join(OUT, "g13_energy_score.npz")))
 
 
+def main_g14():
+    """G14 one training step of the score model: the imported reference's own train_score_func pieces (posenet_agent.py:285-305:
+    net.train(), pts_feature, collect_score_loss -> losses.py:47-89, update_network -> Adam + grad clipping, ema.update) on 4 clouds,
+    repeat_num = 2, with the loss's torch.rand / torch.randn_like draws logged.  (train_score_func itself also writes to a
+    tensorboard writer that only exists with cfg.is_train.)"""
+    ns = ref_import.load()
+    from networks.gf_algorithms.score_utils import ExponentialMovingAverage  # the reference's own (importable after load())
+    ag, sd = make_agent(ns, "score")
+    ag.cfg.repeat_num, ag.cfg.grad_clip = 2, 1.0
+    ag.ema = ExponentialMovingAverage(ag.net.parameters(), decay=ag.cfg.ema_rate)  # built on the loaded weights
+    B = 4
+    pts = torch.from_numpy(synth.make_batch(B, start=800))
+    centre = pts.mean(dim=1)
+    gen = torch.Generator().manual_seed(14)
+    a = torch.nn.functional.normalize(torch.randn(B, 3, generator=gen), dim=-1)
+    b = torch.randn(B, 3, generator=gen)
+    b = torch.nn.functional.normalize(b - (a * b).sum(-1, keepdim=True) * a, dim=-1)
+    gt = torch.cat([a, b, 0.05 * torch.randn(B, 3, generator=gen)], dim=-1)
+    data = {"pts": pts, "zero_mean_pts": pts - centre.unsqueeze(1), "pts_center": centre, "zero_mean_gt_pose": gt}
+    draws_u, draws_z = [], []
+    _rand, _randn_like = torch.rand, torch.randn_like
+
+    def rand(*a_, **k):
+        r = _rand(*a_, **k)
+        draws_u.append(r.detach().clone())
+        return r
+
+    def randn_like(x, **k):
+        r = _randn_like(x, **k)
+        draws_z.append(r.detach().clone())
+        return r
+
+    torch.manual_seed(1414)
+    torch.set_grad_enabled(True)
+    torch.rand, torch.randn_like = rand, randn_like
+    try:
+        ag.net.train()
+        data["pts_feat"] = ag.net(data, mode="pts_feature")
+        losses = ag.collect_score_loss(data)
+        ag.update_network(losses)
+        ag.ema.update(ag.net.parameters())
+    finally:
+        torch.rand, torch.randn_like = _rand, _randn_like
+        torch.set_grad_enabled(False)
+    assert len(draws_u) == 2 and len(draws_z) == 2
+    names = [n for n, p_ in ag.net.named_parameters() if p_.requires_grad]
+    params = dict(ag.net.named_parameters())
+    shadow = dict(zip(names, ag.ema.shadow_params))
+    g14 = {"pts": pts.numpy(), "gt_pose": gt.numpy(), "u": torch.stack(draws_u).numpy(), "z": torch.stack(draws_z).numpy(),
+           "loss": np.float64(losses["gf"].item()), "param_names": np.array(names),
+           "grad_norms": np.array([float(params[n].grad.norm()) for n in names]),
+           "lr": np.float64(ag.cfg.lr), "ema_rate": np.float64(ag.cfg.ema_rate)}
+    for tag, n in (("enc0", "pts_encoder.SA_modules.0.mlps.0.layer0.conv.weight"), ("enc3bn", "pts_encoder.SA_modules.3.mlps.1.layer2.bn.bn.weight"),
+                   ("pose0", "pose_score_net.pose_encoder.0.weight"), ("tail", "pose_score_net.fusion_tail_trans.2.weight")):
+        g14[f"{tag}_grad"] = params[n].grad.numpy().copy()
+        g14[f"{tag}_new"] = params[n].detach().numpy().copy()
+        g14[f"{tag}_ema"] = shadow[n].numpy().copy()
+    bn = ag.net.pts_encoder.SA_modules[0].mlps[0].layer0.bn.bn
+    g14["bn0_running_mean"], g14["bn0_running_var"] = bn.running_mean.numpy().copy(), bn.running_var.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g14_train_step.npz"), **g14)
+    print("g14_train_step.npz", os.path.getsize(os.path.join(OUT, "g14_train_step.npz")), "loss", g14["loss"])
+
+
 if __name__ == "__main__":
+    if "--g14" in sys.argv:
+        sys.exit(main_g14())
     if "--g13" in sys.argv:
         sys.exit(main_g13())
     if "--g12" in sys.argv:
