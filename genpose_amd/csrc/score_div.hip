@@ -15,7 +15,7 @@ using namespace gp_trunk;
 constexpr int DP = 16, DNW = TrunkCfg<DP>::NW, DNV = TrunkCfg<DP>::NV, DNT = TrunkCfg<DP>::NT;
 static_assert(DNW == 4 && DNV == 4, "the backward layers assume 4 waves x 4 chunks");
 constexpr int LDG = HEADS + GP_LD_PAD;                       // row stride of the head-layer gradient G3 [P][768]
-constexpr int OFF_G3 = TrunkLds<DP>::TOTAL;                  // after the trunk's own LDS
+constexpr int OFF_G3 = TrunkLds<DP, true>::TOTAL;                  // after the trunk's own LDS
 constexpr int OFF_U = OFF_G3 + DP * LDG;                     // u = eps / (sigma + 1e-7) [P][12], eps [P][12]
 constexpr int DIV_LDS_FLOATS = OFF_U + 2 * DP * 12;
 
@@ -46,7 +46,7 @@ template <int MODE>
 __global__ __launch_bounds__(DNT) void score_div_kernel(int nrows, int kcand, gp_scorenet net, const float *__restrict__ cvec,
                                                         const float *__restrict__ tvec, const float *__restrict__ x, const float *__restrict__ eps,
                                                         const float *__restrict__ sigma_dev, float *__restrict__ score, float *__restrict__ div) {
-    using L = TrunkLds<DP>;
+    using L = TrunkLds<DP, true>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int row0 = blockIdx.x * DP, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *X0 = lds, *H1 = lds + L::OFF_H1, *H2 = lds + L::OFF_H2, *G3 = lds + OFF_G3, *U = lds + OFF_U, *E = U + DP * 12;

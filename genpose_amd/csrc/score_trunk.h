@@ -28,16 +28,28 @@ struct TrunkCfg {
 };
 
 // LDS layout for a P-row tile (floats):
-//   X0 [P][16+8] | H1 [P][256+8] | H2 [P][256+8] | red [4*NW][P][12] | wout [9][256] | cvt [2][768+16]
+//   X0 [P][16+8] | H1 [P][256+8] | H2 [P][256+8] | red [4*NW][P][12] | wout [9][256] | cvt [2][768+16]        (16-row tiles)
+//   X0 [P][16+8] | H1 = H2 [P][256+8]            | red [NW][P][12]   | wout [9][256] | cvt [2][768+16]        (compact form)
 // wout / cvt = the head epilogue's operands, staged once per launch while the prologue waits on its own loads:
 // cvt[c] = cvec[first cloud of the tile + c] + tvec.  (Read back with broadcast ds_read_b128; fetching them from global
 // memory in the epilogue costs 1.1-1.7 k cycles per head, and requesting them under the MFMA loop slows the weight
 // stream by more than that - the vector memory path is the loop's bottleneck.)
-template <int P>
+// Compact form (GP_TRUNK_DIET_MINP, default: tiles of >= 32 rows): layer 2 runs IN PLACE (H2 aliases H1; every wave keeps its
+// outputs in the accumulators until all waves have read H1) and the four lane groups of a wave are combined in registers
+// (v_permlane16/32_swap) before parking: red [NW][P][12].  The 32-row tile takes 64.6 KB instead of 135 KB - a workgroup of another
+// kernel (furthest point sampling, an SA chain kernel of the next batch's encoder) can share the CU with it - and the launch got
+// 3 % FASTER on its own (77.3 -> 75.0 us at 16 000 rows: 37 KB less LDS traffic per head epilogue).  KEEP (the backward pass of
+// gp_score_div reads both hidden activations) keeps H1 and H2 apart.
+#ifndef GP_TRUNK_DIET_MINP
+#define GP_TRUNK_DIET_MINP 32
+#endif
+template <int P, bool KEEP = false>
 struct TrunkLds {
+    static constexpr bool COMPACT = P >= GP_TRUNK_DIET_MINP, INPLACE = COMPACT && !KEEP;
     static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD, LDC = HEADS + 16;
-    static constexpr int OFF_H1 = P * LD0, OFF_H2 = OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH,
-                         OFF_WOUT = OFF_RED + 4 * TrunkCfg<P>::NW * P * 12, OFF_CVT = OFF_WOUT + POSE * HID,
+    static constexpr int OFF_H1 = P * LD0, OFF_H2 = INPLACE ? OFF_H1 : OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH,
+                         NRED = (COMPACT ? 1 : 4) * TrunkCfg<P>::NW,
+                         OFF_WOUT = OFF_RED + NRED * P * 12, OFF_CVT = OFF_WOUT + POSE * HID,
                          TOTAL = OFF_CVT + 2 * LDC;
 };
 
@@ -100,9 +112,9 @@ __device__ __forceinline__ void trunk_begin(const gp_scorenet &net, TrunkPre<P> 
 }
 
 // parks the staged epilogue operands in LDS (visible after the next __syncthreads())
-template <int P>
+template <int P, bool KEEP = false>
 __device__ __forceinline__ void trunk_park_epi(float *lds, TrunkPre<P> &pre) {
-    using L = TrunkLds<P>;
+    using L = TrunkLds<P, KEEP>;
     constexpr int NT = TrunkCfg<P>::NT;
 #pragma unroll
     for (int q = 0; q < TrunkPre<P>::NWO; ++q) {
@@ -122,7 +134,8 @@ __device__ __forceinline__ void trunk_park_epi(float *lds, TrunkPre<P> &pre) {
 }
 
 // dense 256-wide layer of the trunk on pre-requested weights and bias: out = relu(X W^T + b) -> LDS.
-template <int PT, int NW>
+// SYNC_BEFORE_STORE: Ys aliases Xs (in-place layer): every wave has finished reading Xs before any wave overwrites it.
+template <int PT, int NW, bool SYNC_BEFORE_STORE = false>
 __device__ __forceinline__ void trunk_dense(WStages<16 / NW> &st, const f32x4 (&bias)[16 / NW], const float *Xs, int ld,
                                             const float *__restrict__ Wp, int K, float *Ys, int ldo) {
     constexpr int NV = 16 / NW;
@@ -130,6 +143,7 @@ __device__ __forceinline__ void trunk_dense(WStages<16 / NW> &st, const f32x4 (&
     const int nc[4] = {wave, wave + NW, wave + 2 * NW, wave + 3 * NW};
     f32x4 acc[4][PT];
     mfma_run<NV, PT>(st, Xs, ld, 0, Wp, gp_round16(K) / 16, HID / 16, nc, acc);
+    if constexpr (SYNC_BEFORE_STORE) __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int ch = nc[i] * 16 + 4 * (lane >> 4);
@@ -145,16 +159,26 @@ __device__ __forceinline__ void trunk_dense(WStages<16 / NW> &st, const f32x4 (&
     }
 }
 
+// sum over the four 16-lane groups of a wave, result in every lane; fixed order ((g0 + g1) + (g2 + g3)): deterministic
+__device__ __forceinline__ float lane_groups_sum(float v) {
+    const int a = __float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);  // {g0,g0,g2,g2} , {g1,g1,g3,g3}
+    const float s = __int_as_float(r[0]) + __int_as_float(r[1]);
+    const int b = __float_as_int(s);
+    const auto q = __builtin_amdgcn_permlane32_swap(b, b, false, false);  // {lo,lo} , {hi,hi}
+    return __int_as_float(q[0]) + __int_as_float(q[1]);
+}
+
 // epilogue operands of one head for this wave's 16-channel chunks: cv = cvec[cloud of the row] + tvec (pre-added)
 template <int PT, int NV>
 struct HeadOps {
     f32x4 w0[NV], w1[NV], w2[NV], cv[NV][PT];
 };
 
-template <int P, int PT, int NV>
+template <int P, int PT, int NV, bool KEEP = false>
 __device__ __forceinline__ void head_ops_load(HeadOps<PT, NV> &o, const float *lds, bool staged, const float *__restrict__ cvec,
                                               const float *__restrict__ tvec, int h, const int (&nc)[4], const int (&cloud)[PT], int cloud0) {
-    using L = TrunkLds<P>;
+    using L = TrunkLds<P, KEEP>;
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -185,7 +209,7 @@ struct TrunkNoEmit {};
 template <int P, bool KEEP_H1 = false, class Emit = TrunkNoEmit>
 __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net, const float *__restrict__ cvec, const float *__restrict__ tvec,
                                              int row0, int nrows, int kcand, TrunkPre<P> &pre, Emit emit = Emit()) {
-    using L = TrunkLds<P>;
+    using L = TrunkLds<P, KEEP_H1>;
     constexpr int PT = P / 16, NW = TrunkCfg<P>::NW, NV = TrunkCfg<P>::NV, NT = TrunkCfg<P>::NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *X0 = lds, *H1 = lds + L::OFF_H1, *H2 = lds + L::OFF_H2, *red = lds + L::OFF_RED;
@@ -202,7 +226,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         if (r >= nrows) r = nrows - 1;
         cloud[p] = r / kcand;
     }
-    trunk_park_epi<P>(lds, pre);  // visible after the barrier that follows layer 1
+    trunk_park_epi<P, KEEP_H1>(lds, pre);  // visible after the barrier that follows layer 1
     GP_T(2);
     // ---- layer 1 (9 -> 256); layer 2's first weight stages and bias are requested before it runs
     WStages<NV> stB;
@@ -216,7 +240,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
     // ---- layer 2 (256 -> 256); head 0's weights (and, small tile, its epilogue operands) requested before it runs
     WStages<NV> stH[2];
     mfma_preload<NV>(stH[0], net.w_headx, HID / 16, HEADS / 16, nch[0]);
-    trunk_dense<PT, NW>(stB, b2, H1, L::LDH, net.w_pose2, HID, H2, L::LDH);
+    trunk_dense<PT, NW, L::INPLACE>(stB, b2, H1, L::LDH, net.w_pose2, HID, H2, L::LDH);
     GP_T(4);
     __syncthreads();
     GP_T(5);
@@ -242,7 +266,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
             }
 #else
         HeadOps<PT, NV> o;
-        head_ops_load<P, PT, NV>(o, lds, pre.staged, cvec, tvec, h, nch[h], cloud, pre.cloud0);
+        head_ops_load<P, PT, NV, KEEP_H1>(o, lds, pre.staged, cvec, tvec, h, nch[h], cloud, pre.cloud0);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
 #pragma unroll
@@ -259,11 +283,25 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
             }
         }
 #endif
-        // every lane parks its partial sums; the 4 channel groups x 4 waves are combined below in a fixed order
+        if constexpr (L::COMPACT) {
+            // the 4 channel groups of the wave are summed in registers, one partial per wave is parked
 #pragma unroll
-        for (int p = 0; p < PT; ++p)
+            for (int p = 0; p < PT; ++p)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) red[((wave * 4 + (lane >> 4)) * P + p * 16 + (lane & 15)) * 12 + 3 * h + c] = part[p][c];
+                for (int c = 0; c < 3; ++c) part[p][c] = lane_groups_sum(part[p][c]);
+            if (lane < 16) {
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) red[(wave * P + p * 16 + lane) * 12 + 3 * h + c] = part[p][c];
+            }
+        } else {
+            // every lane parks its partial sums; the 4 channel groups x NW waves are combined below in a fixed order
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) red[((wave * 4 + (lane >> 4)) * P + p * 16 + (lane & 15)) * 12 + 3 * h + c] = part[p][c];
+        }
         GP_T(8 + 3 * h);
     }
     __syncthreads();
@@ -275,7 +313,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
             const int r = e / POSE, j = e - r * POSE;
             float v = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4 * NW; ++q) v += red[(q * P + r) * 12 + j];
+            for (int q = 0; q < L::NRED; ++q) v += red[(q * P + r) * 12 + j];
             if constexpr (KEEP_H1)
                 X0[r * L::LD0 + 12 + j] = v + pre.bout[it];  // x sits in columns 0..8; 12..20 are padding by now
             else
