@@ -1,4 +1,4 @@
-"""profiles/r1_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) per microbench shape.
+"""profiles/r<N>_pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) per microbench shape.
 usage: python scratch/pmc_traffic.py out.json  B:fetch_db:write_db [B:fetch_db:write_db ...]      (K = 50)"""
 import json, re, sqlite3, sys
 from collections import defaultdict
