@@ -55,6 +55,13 @@ __device__ __forceinline__ unsigned long long wave_max_key(uint32_t dkey, uint32
     return ((unsigned long long)m << 32) | r;
 }
 
+// LDS-qualified pointers: with plain `const float *` the planes travel through a pointer array and the winner's coordinates are
+// fetched with flat_load (the slow aperture path, on the critical path of every selected point) instead of ds_read.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef const lds_f32 *lds_cptr;
+template <typename T>
+__device__ __forceinline__ lds_cptr as_lds(const T *p) { return (lds_cptr)(p); }
+
 constexpr int FPS_T = 256;       // threads per cloud
 constexpr int FPS_MAXPPT = 16;   // register-resident points per thread (n <= 4096)
 
@@ -94,7 +101,7 @@ __device__ __forceinline__ FpsRank make_rank(int n) {
 // One FPS pass over the n points held in LDS (sx/sy/sz) selecting m of them.
 // temp_io: optional global running-min buffer (API semantics) - read at start, written back at the end.
 template <int PPT, bool FULL = false>  // FULL: n == PPT * FPS_T exactly (no bounds checks in the hot loop)
-__device__ void fps_pass(int n, int m, const float *sx, const float *sy, const float *sz, float *temp_io,
+__device__ void fps_pass(int n, int m, lds_cptr sx, lds_cptr sy, lds_cptr sz, float *temp_io,
                          int32_t *idx_out, unsigned long long (*slots)[FPS_T / 64]) {
     const int tid = threadIdx.x;
     const FpsRank rk = make_rank(n);
@@ -119,10 +126,12 @@ __device__ void fps_pass(int n, int m, const float *sx, const float *sy, const f
         for (int j = 0; j < PPT; ++j) {
             int k = tid + j * FPS_T;
             if (FULL || k < n) {
-                float d = sqdist(px[j], py[j], pz[j], x1, y1, z1);
-                float d2 = fminf(d, tmp[j]);
-                tmp[j] = d2;
-                const uint32_t dk = fkey(d2);
+                const float d = sqdist(px[j], py[j], pz[j], x1, y1, z1);
+                // fminf(d, tmp) on the bit patterns: squared distances and the running minimum are >= 0 (finite clouds: never NaN),
+                // where the unsigned order of the bits IS the float order - one v_min_u32 instead of canonicalise + v_min_f32
+                const uint32_t du = __float_as_uint(d), tu = __float_as_uint(tmp[j]);
+                tmp[j] = __uint_as_float(du < tu ? du : tu);
+                const uint32_t dk = fkey(tmp[j]);
                 const bool better = dk > bd || (dk == bd && rnk[j] > br);
                 bd = better ? dk : bd;
                 br = better ? rnk[j] : br;
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(int n, int m, const float *_
         (c == 0 ? sx : c == 1 ? sy : sz)[k] = v;
     }
     __syncthreads();
-    fps_pass<PPT>(n, m, sx, sy, sz, temp, idx, slots);
+    fps_pass<PPT>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), temp, idx, slots);
 }
 
 __global__ __launch_bounds__(FPS_T) void fps_big_kernel(int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
@@ -241,17 +250,17 @@ __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
         float *sx = plane[buf], *sy = plane[buf] + cap[buf], *sz = plane[buf] + 2 * cap[buf];
         float *nx = plane[buf ^ 1], *ny = plane[buf ^ 1] + cap[buf ^ 1], *nz = plane[buf ^ 1] + 2 * cap[buf ^ 1];
         if (n == 4 * FPS_T)
-            fps_pass<4, true>(n, m, sx, sy, sz, nullptr, sel, slots);
+            fps_pass<4, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else if (n == 2 * FPS_T)
-            fps_pass<2, true>(n, m, sx, sy, sz, nullptr, sel, slots);
+            fps_pass<2, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else if (n == FPS_T)
-            fps_pass<1, true>(n, m, sx, sy, sz, nullptr, sel, slots);
+            fps_pass<1, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else if (n <= FPS_T)
-            fps_pass<1>(n, m, sx, sy, sz, nullptr, sel, slots);
+            fps_pass<1>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else if (n <= 2 * FPS_T)
-            fps_pass<2>(n, m, sx, sy, sz, nullptr, sel, slots);
+            fps_pass<2>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else
-            fps_pass<4>(n, m, sx, sy, sz, nullptr, sel, slots);
+            fps_pass<4>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         __syncthreads();
         int32_t *gi = a.idx[l] + (size_t)b * m;
         float *gx = a.new_xyz[l] + (size_t)b * m * 3;
