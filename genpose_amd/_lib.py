@@ -53,6 +53,7 @@ SIGNATURES = {
     "gp_energy_score": [c_int, c_int, NETP, P, P, P, P, P, P, P],
     "gp_pc_tile_rows": [c_int, c_int, c_int],
     "gp_pc_step_grouped": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
+    "gp_pc_step_coupled": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 12 + [P],
     "gp_rk45_state_bytes": [],
     "gp_rk45_state_layout": [ctypes.POINTER(c_int64), c_int],
     "gp_rk45_set_dense": [P, P, c_int, P, P],

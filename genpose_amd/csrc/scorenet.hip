@@ -123,6 +123,8 @@ struct PcArgs {
     const float *z_lang, *z_pred;    // [nsteps][R][9]
     const float *centre;             // [R/k... per cloud][3]
     float *x, *mean_x, *score, *partials, *traj;  // x,mean_x,score [R,9]; partials [nsteps][nblocks]; traj [nsteps][R][9] or null
+    const float *gn_ext;             // [nsteps][ngroups] or null: the batch-mean gradient norm supplied from outside (a batch that is
+    int ngroups;                     //   sharded over several GPUs: the mean over ALL its rows, all-reduced between the launches)
 };
 
 // Kernel for step i (0 <= i <= nsteps):
@@ -178,7 +180,9 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
             cen[0] = cp[0], cen[1] = cp[1], cen[2] = cp[2];
         }
         constexpr int LASTW = TrunkCfg<P>::NT - 64;
-        if (tid >= LASTW) {
+        if (a.gn_ext) {
+            if (tid == LASTW) s_gn = a.gn_ext[(size_t)(i - 1) * a.ngroups + blockIdx.x / a.bpg];
+        } else if (tid >= LASTW) {
             float s = 0.f;
             const float *pp = a.partials + (size_t)(i - 1) * a.nblocks + (size_t)(blockIdx.x / a.bpg) * a.bpg;
             for (int q = tid - LASTW; q < a.bpg; q += 64) s += pp[q];
@@ -342,6 +346,13 @@ int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k) {
 int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
                        float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s) {
+    return gp_pc_step_coupled(ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x,
+                              score, partials, traj, nullptr, s);
+}
+
+int gp_pc_step_coupled(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+                       const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
+                       float *x, float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
     if (ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || step < 0 || step > nsteps || !net || !cvec || !tvec_all || !sched || !z_langevin ||
         !z_predictor || !centre || !x || !mean_x || !score || !partials)
         return GP_EINVAL;
@@ -354,6 +365,7 @@ int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int 
     a.bpg = (rg + P - 1) / P, a.rows_per_group = rg, a.nblocks = a.bpg * ngroups;
     a.cvec = cvec, a.tvec_all = tvec_all, a.sched = sched, a.z_lang = z_langevin, a.z_pred = z_predictor, a.centre = centre;
     a.x = x, a.mean_x = mean_x, a.score = score, a.partials = partials, a.traj = traj;
+    a.gn_ext = gn_ext, a.ngroups = ngroups;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(pc_step_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -125,7 +125,10 @@ class GFObjectPose:
             key = ("pc", B, K, n, return_process)
             smp = self._samplers.get(key)
             if smp is None:
-                smp = self._samplers[key] = PCSampler(self.pose_score_net, B, K, n, self.device, record_traj=return_process)
+                # self.coupling_group (optional, set by the caller): the batch is sharded over the ranks of that process group and
+                # the Langevin step size is taken over ALL of its rows (PCSampler, "faithful" multi-GPU mode)
+                smp = self._samplers[key] = PCSampler(self.pose_score_net, B, K, n, self.device, record_traj=return_process,
+                                                      coupling_group=getattr(self, "coupling_group", None))
             z1, z2 = noise if noise is not None else (None, None)
             xs, res = smp.run(cvec, centre, x0, z1, z2)
             return (xs.clone() if xs is not None else None), res.clone()

@@ -25,9 +25,15 @@ def pc_schedule(num_steps, eps=EPS):
 class PCSampler:
     """Predictor-corrector sampler state for a fixed (B, K, num_steps): buffers + optional hipGraph of the whole loop."""
 
-    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1):
+    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1, coupling_group=None):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: one launch chain serves all of
-        them, the batch-mean gradient norm (samplers.py:130-132) stays per batch (gp_pc_step_grouped)."""
+        them, the batch-mean gradient norm (samplers.py:130-132) stays per batch (gp_pc_step_grouped).
+
+        coupling_group (a torch.distributed process group; "faithful" multi-GPU mode, SURVEY §8e caveat): this rank's B clouds are
+        one SHARD of a batch that is spread over the ranks of the group (equal shards).  After every step the per-batch sums of
+        |score| are all-reduced (one float per batch) and the next launch takes the mean over ALL rows of the batch
+        (gp_pc_step_coupled), so every shard steps exactly as the unsharded batch would.  The loop then runs launch by launch (an
+        all-reduce sits between consecutive launches), not as one captured graph."""
         if B % groups:
             raise ValueError(f"{B} clouds do not split into {groups} equal batches")
         self.net, self.B, self.K, self.n, self.groups = net, B, K, num_steps, groups
@@ -47,18 +53,31 @@ class PCSampler:
         self.z1, self.z2 = f(num_steps, R, 9), f(num_steps, R, 9)
         self.cvec, self.centre = f(B, 768), f(B, 3)
         self.traj = f(num_steps, R, 9) if record_traj else None
+        self.coupling_group = coupling_group
+        self.gn_ext = None
+        if coupling_group is not None:
+            import torch.distributed as dist
+            self._dist = dist
+            self._world = dist.get_world_size(coupling_group)
+            self.gn_ext = torch.zeros(num_steps, groups, device=self.dev)
+            use_graph = False
         self.use_graph = use_graph
         self.graph = None
 
     def launch_step(self, i):
         """Launch i of the chain (0 <= i <= n) on the current stream: finishes step i-1 and, for i < n, evaluates the score at t_i."""
-        _lib.call("gp_pc_step_grouped", self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
+        _lib.call("gp_pc_step_coupled", self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
                   ptr(self.sched), ptr(self.z1), ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
-                  ptr(self.traj), stream_ptr())
+                  ptr(self.traj), ptr(self.gn_ext), stream_ptr())
 
     def _launch_all(self):
         for i in range(self.n + 1):
             self.launch_step(i)
+            if self.coupling_group is not None and i < self.n:
+                # sum of |score_i| over this shard's rows, per batch -> over all shards -> mean over all rows of the batch
+                tot = self.partials[i].view(self.groups, -1).sum(dim=1)
+                self._dist.all_reduce(tot, op=self._dist.ReduceOp.SUM, group=self.coupling_group)
+                self.gn_ext[i].copy_(tot / float(self.R // self.groups * self._world))
 
     def run(self, cvec, centre, init_x, z_langevin=None, z_predictor=None, slot_free_event=None, graph_events=None):
         """cvec [B,768], centre [B,3], init_x [R,9]; noise [n,R,9] (drawn on the device generator if None).

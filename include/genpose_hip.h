@@ -210,6 +210,15 @@ int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int 
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor,
                        const float *centre, float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s);
 
+/* The same launch with the batch-mean gradient norm SUPPLIED: gn_ext [nsteps][ngroups] (device) holds, for step i, the mean of
+ * |score_i| over ALL rows of the batch each group belongs to.  For a batch that is sharded over several GPUs (SURVEY §8e caveat): the
+ * host sums this rank's `partials` of step i, all-reduces the sum across the ranks and writes gn_ext[i] before launching step i+1, so
+ * every shard takes the Langevin step size the unsharded batch would take (samplers.py:130-132).  gn_ext == NULL: gp_pc_step_grouped. */
+int gp_pc_step_coupled(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+                       const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor,
+                       const float *centre, float *x, float *mean_x, float *score, float *partials, float *traj, const float *gn_ext,
+                       gp_stream_t s);
+
 /* Probability-flow ODE sampler = cond_ode_sampler (samplers.py:163-227) over scipy's RK45 (rk.py / common.py):
  * Dormand-Prince 5(4), f64 state and controller resident in device memory, f32 score network, batch-global RMS
  * error norm, SAFETY 0.9 / MIN_FACTOR 0.2 / MAX_FACTOR 10, Hairer initial step.
