@@ -1,7 +1,8 @@
 """GPU parity at the sizes BASELINE.json's configs are quoted on (the sizes bench.py times), not scaled-down stand-ins:
 
-  configs[1]  5 x 64 clouds x 1024 pts, K = 50, PC sampler with 100 steps: one whole batch against the CPU oracle, every batch through
-              size-independent properties, request batching (5 batches per launch, 32-row tiles) against one batch per launch (16-row tiles)
+  configs[1]  G x 64 clouds x 1024 pts (G = bench.py's default request batching), K = 50, PC sampler with 100 steps: one whole batch against
+              the CPU oracle, every batch through size-independent properties, G batches per launch (32-row tiles) against one batch per
+              launch (16-row tiles)
   encoder     64 and 320 clouds against the oracle
   configs[2]  256 clouds: score model + energy model + ranking + aggregation in FullPipelinePredictor against the agents called one
               after the other, the oracle on a 16-cloud slice, and the exact ranking permutation on all 256
@@ -74,11 +75,12 @@ def _check_pose_properties(pred):
 
 
 def test_config1_as_timed():
-    """BASELINE configs[1] exactly as bench.py times it: PipelinedPCPredictor(batches_per_launch=5) on 5 x 64 synthetic clouds,
-    K = 50, 100 PC steps (16 000 rows per launch, 32-row tiles), with injected prior / Langevin / predictor draws."""
+    """BASELINE configs[1] exactly as bench.py times it: PipelinedPCPredictor(batches_per_launch=G) on G x 64 synthetic clouds (G = the
+    bench's default: 10 -> 32 000 rows per launch, 32-row tiles), K = 50, 100 PC steps, with injected prior / Langevin / predictor draws."""
+    import bench
     from genpose_amd import synth
     from genpose_amd.pipeline import PipelinedPCPredictor
-    B1, K, n, G = 64, 50, 100, 5
+    B1, K, n, G = 64, 50, 100, bench.DEFAULT_BATCHES_PER_LAUNCH  # the bench's own default request batching
     R1 = B1 * K
     agent = make_agent("score", "pc", n)
     batches = [torch.from_numpy(synth.make_batch(B1, start=B1 * i)).cuda() for i in range(G)]
@@ -87,7 +89,7 @@ def test_config1_as_timed():
     noises = [(torch.randn(n, R1, 9, generator=gen), torch.randn(n, R1, 9, generator=gen)) for _ in range(G)]
     noises_dev = [(a.cuda(), b.cuda()) for a, b in noises]
     pipe5 = PipelinedPCPredictor(agent, B1, K, n, batches_per_launch=G)
-    assert pipe5._sampler(0, G).tile == 32 and pipe5._sampler(0, G).R == 16000
+    assert pipe5._sampler(0, G).tile == 32 and pipe5._sampler(0, G).R == G * R1
     got5 = [g.clone() for g in pipe5.run(batches, prior_noise=[p.cuda() for p in priors], noise=noises_dev)]
     torch.cuda.synchronize()
     for g in got5:
@@ -103,9 +105,9 @@ def test_config1_as_timed():
     assert pipe1._sampler(0, 1).tile == 16
     got1 = pipe1.run(batches, prior_noise=[p.cuda() for p in priors], noise=noises_dev)
     torch.cuda.synchronize()
-    _assert_pc100_close(torch.stack(got5).cpu().numpy(), torch.stack(list(got1)).cpu().numpy(), "configs[1] 5-per-launch vs 1-per-launch")
+    _assert_pc100_close(torch.stack(got5).cpu().numpy(), torch.stack(list(got1)).cpu().numpy(), f"configs[1] {G}-per-launch vs 1-per-launch")
     # one WHOLE batch (the middle one) against the CPU oracle: encoder + 100-step PC sampler with the same draws
-    i = 2
+    i = G // 2
     pts_cpu = batches[i].cpu()
     ref = _oracle_pc(go.make_state_dict(0, "score"), pts_cpu, K, priors[i], n, noises[i][0], noises[i][1])
     _assert_pc100_close(got5[i].cpu().numpy(), ref.numpy(), f"configs[1] batch {i} (3200 rows x 100 steps) vs oracle")
