@@ -138,7 +138,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_gn;
     const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
-    // GP_ABL_*: ablation builds (tuning; scratch/r2_call4.sh, profiles/r2_sampler_ablation.txt) - what each phase of a launch costs
+    // GP_ABL_*: ablation builds (tuning; scratch/r2_ablation.sh, profiles/r2_sampler_ablation.txt) - what each phase of a launch costs
 #ifdef GP_ABL_EMPTY  // the launch itself
     return;
 #endif
