@@ -137,7 +137,6 @@ class Pointnet2EncoderHIP:
         ws = self._workspace(B, N, slot)
         st = stream_ptr()
         cfg = self.cfg
-        group_levels = [k for k, npnt in enumerate(cfg["npoints"]) if npnt is not None]
         if grouping is not None:
             if grouping.get("_grouping_key") != self.grouping_key() or grouping["new_xyz"][0].shape[0] != B:
                 raise ValueError("grouping comes from an encoder with a different configuration / batch")
