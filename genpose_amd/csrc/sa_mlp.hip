@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentre
 #pragma unroll
         for (int r = 0; r < 4; ++r) w1[q][r] = *reinterpret_cast<const f32x4 *>(a.wxyz + (16 * q + 4 * g + r) * 4);
     }
-    f32x4 w2[Q2][Q1], bb2[Q2], w3[Q3][Q2], bb3[Q3];
+    f32x4 w2[Q2][Q1], bb2[Q2], w3[Q3][Q2];
+    float bb3[Q3];  // last layer runs transposed (lane = channel 16 n + pt): one bias per lane and chunk
 #pragma unroll
     for (int n = 0; n < Q2; ++n) {
         bb2[n] = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * n + 4 * g);
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentre
     }
 #pragma unroll
     for (int n = 0; n < Q3; ++n) {
-        bb3[n] = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * n + 4 * g);
+        bb3[n] = a.b3[16 * n + pt];
 #pragma unroll
         for (int q = 0; q < Q2; ++q) w3[n][q] = reinterpret_cast<const f32x4 *>(a.w3)[((size_t)q * Q3 + n) * 64 + lane];
     }
@@ -350,9 +351,7 @@ __global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentre
     for (; c < ncentres_total; c += nwaves) {
         load_d(c + nwaves, jn, dn);
         load_idx(c + 2 * nwaves, jnn);
-        f32x4 res[Q3];
-#pragma unroll
-        for (int n = 0; n < Q3; ++n) res[n] = f32x4{0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0
+        float res[Q3];  // running max over the neighbourhood's rows of the PRE-bias layer-3 output, per channel 16 n + pt
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const float dx = dcur[p][0], dy = dcur[p][1], dz = dcur[p][2];
@@ -366,36 +365,47 @@ __global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentre
                 v.w += w1[q][3].x * dx + w1[q][3].y * dy + w1[q][3].z * dz;
                 h1[q] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
             }
+            // every output chunk of a layer has its own accumulator and the chunks are interleaved k-step by k-step: consecutive
+            // MFMAs never wait on each other's result (40-cycle dependent latency against a 32-cycle issue interval)
+            {
+                f32x4 acc[Q2];
 #pragma unroll
-            for (int n = 0; n < Q2; ++n) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int n = 0; n < Q2; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < Q1; ++q)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[n][q][jj], h1[q][jj], acc, 0, 0, 0);
-                acc += bb2[n];
-                h2[n] = f32x4{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
-            }
+                    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int n = 0; n < Q3; ++n) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        for (int n = 0; n < Q2; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[n][q][jj], h1[q][jj], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < Q2; ++n) {
+                    const f32x4 v = acc[n] + bb2[n];
+                    h2[n] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                }
+            }
+            {
+                // last layer TRANSPOSED (activations as the A operand): lane = channel, registers x lane groups = the 16 rows
+                f32x4 acc[Q3];
+#pragma unroll
+                for (int n = 0; n < Q3; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < Q2; ++q)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[n][q][jj], h2[q][jj], acc, 0, 0, 0);
-                acc += bb3[n];
-                res[n].x = fmaxf(res[n].x, acc.x);
-                res[n].y = fmaxf(res[n].y, acc.y);
-                res[n].z = fmaxf(res[n].z, acc.z);
-                res[n].w = fmaxf(res[n].w, acc.w);
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int n = 0; n < Q3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[q][jj], w3[n][q][jj], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < Q3; ++n) {
+                    const float m = points16_max_t(acc[n]);
+                    res[n] = p == 0 ? m : fmaxf(res[n], m);
+                }
             }
         }
+        // max_i relu(x_i + b) = relu(max_i x_i + b): bias and ReLU once per channel, after the pooling (exact: rounding is monotone)
         float *o = a.out + (size_t)c * a.cout_total + a.cout_off;
 #pragma unroll
-        for (int n = 0; n < Q3; ++n) {
-            f32x4 m = {row16_max(res[n].x), row16_max(res[n].y), row16_max(res[n].z), row16_max(res[n].w)};
-            if (pt == 0) *reinterpret_cast<f32x4 *>(o + 16 * n + 4 * g) = m;
-        }
+        for (int n = 0; n < Q3; ++n)
+            if (g == 0) o[16 * n + pt] = fmaxf(res[n] + bb3[n], 0.f);
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             dcur[p][0] = dn[p][0], dcur[p][1] = dn[p][1], dcur[p][2] = dn[p][2];
@@ -424,11 +434,12 @@ __global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncen
         w.w = a.b1[e];
         w1l[e] = w;
     }
-    f32x4 bb2[Q2], bb3[Q3];
+    f32x4 bb2[Q2];
+    float bb3[Q3];  // the last layer runs transposed (lane = channel 16 n + pt, see points16_max_t): one bias per lane and chunk
 #pragma unroll
     for (int n = 0; n < Q2; ++n) bb2[n] = *reinterpret_cast<const f32x4 *>(a.b2 + 16 * n + 4 * g);
 #pragma unroll
-    for (int n = 0; n < Q3; ++n) bb3[n] = *reinterpret_cast<const f32x4 *>(a.b3 + 16 * n + 4 * g);
+    for (int n = 0; n < Q3; ++n) bb3[n] = a.b3[16 * n + pt];
     __syncthreads();
     const int wave_global = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
     // The wave walks 16-row chunks: iteration `it` is chunk p = it % PT of the wave's (it / PT)-th neighbourhood, so the
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncen
     jn = load_idx(0);
     load_ops(0, jn, dcur, zcur);
     jn = load_idx(1);
-    f32x4 res[Q3];
+    float res[Q3];  // running max over the neighbourhood's rows of the pre-bias layer-3 output, per channel 16 n + pt
 #pragma unroll 1
     for (int it = 0; it < nits; ++it) {
         load_ops(it + 1, jn, dn, zn);
@@ -475,10 +486,6 @@ __global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncen
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const int p = it % PT;
-        if (p == 0) {
-#pragma unroll
-            for (int n = 0; n < Q3; ++n) res[n] = f32x4{0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0
-        }
         {
             const float dx = dcur[0], dy = dcur[1], dz = dcur[2];
             f32x4 h1[Q1], h2[Q2];
@@ -527,26 +534,22 @@ __global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncen
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h2[q][jj], acc[u], 0, 0, 0);
+                        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[q][jj], wf[u][jj], acc[u], 0, 0, 0);  // transposed
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const f32x4 v = acc[u] + bb3[n0 + u];
-                    res[n0 + u].x = fmaxf(res[n0 + u].x, v.x);
-                    res[n0 + u].y = fmaxf(res[n0 + u].y, v.y);
-                    res[n0 + u].z = fmaxf(res[n0 + u].z, v.z);
-                    res[n0 + u].w = fmaxf(res[n0 + u].w, v.w);
+                    const float m = points16_max_t(acc[u]);
+                    res[n0 + u] = p == 0 ? m : fmaxf(res[n0 + u], m);
                 }
             }
         }
         if (p == PT - 1) {
+            // max_i relu(x_i + b) = relu(max_i x_i + b): bias and ReLU once per channel, after the pooling (exact: rounding is monotone)
             const int c = wave_global + (it / PT) * nwaves;
             float *o = a.out + (size_t)c * a.cout_total + a.cout_off;
 #pragma unroll
-            for (int n = 0; n < Q3; ++n) {
-                f32x4 m = {row16_max(res[n].x), row16_max(res[n].y), row16_max(res[n].z), row16_max(res[n].w)};
-                if (pt == 0) *reinterpret_cast<f32x4 *>(o + 16 * n + 4 * g) = m;
-            }
+            for (int n = 0; n < Q3; ++n)
+                if (g == 0) o[16 * n + pt] = fmaxf(res[n] + bb3[n], 0.f);
         }
         dcur[0] = dn[0], dcur[1] = dn[1], dcur[2] = dn[2];
         jn = jnn;
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc3[n0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h2[q][jj], acc3[n0 + u], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) acc3[n0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[q][jj], wf[u][jj], acc3[n0 + u], 0, 0, 0);  // transposed
 #pragma unroll
                 for (int u = 0; u < 4; ++u) wpre[u] = wn[u];
             }
@@ -734,16 +737,14 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
         {
             const int c = wave_global + (it / PT) * nwaves;
             float *o = a.out + (size_t)(it < nits ? c : 0) * a.cout_total + a.cout_off;
+            // layer 3 ran transposed: lane = channel 16 n + pt, the 16 rows are the registers x lane groups (points16_max_t);
+            // max_i relu(x_i + b) = relu(max_i x_i + b), so bias and ReLU come once per channel after the pooling
 #pragma unroll
             for (int n = 0; n < Q3; ++n) {
-                const f32x4 v = acc3[n] + *reinterpret_cast<const f32x4 *>(a.b3 + 16 * n + 4 * (lo >> 4));
-                f32x4 m = {row16_max(fmaxf(v.x, 0.f)), row16_max(fmaxf(v.y, 0.f)), row16_max(fmaxf(v.z, 0.f)), row16_max(fmaxf(v.w, 0.f))};
-                if (pt == 0 && it < nits) {
-                    f32x4 *op = reinterpret_cast<f32x4 *>(o + 16 * n + 4 * g);
-                    if (p > 0) {  // later chunk of the same neighbourhood: combine with what this lane stored for the earlier one
-                        const f32x4 prev = *op;
-                        m = f32x4{fmaxf(m.x, prev.x), fmaxf(m.y, prev.y), fmaxf(m.z, prev.z), fmaxf(m.w, prev.w)};
-                    }
+                float m = fmaxf(points16_max_t(acc3[n]) + a.b3[16 * n + (lo & 15)], 0.f);
+                if (g == 0 && it < nits) {
+                    float *op = o + 16 * n + pt;
+                    if (p > 0) m = fmaxf(m, *op);  // later chunk of the same neighbourhood: combine with what this lane stored for the earlier one
                     *op = m;
                 }
             }
