@@ -35,7 +35,7 @@ FLOP_ENCODER = 2.201e9     # per cloud per encoder pass
 FLOP_CLOUD_EMBED = 1.573e6
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # Request batching of the default run: consecutive 64-cloud batches that share one encoder pass and one sampler launch chain (each keeps
-# its own batch-global coupling and gets its stand-alone result).  Measured on MI355X: 1 -> 16.5 k, 5 -> 24.3 k, 10 -> 25.0 k, 20 -> 25.4 k
+# its own batch-global coupling and gets its stand-alone result).  Measured on MI355X: 1 -> 16.5 k, 5 -> 24.1 k, 10 -> 25.0 k, 20 -> 25.4 k
 # poses/s (32 000 rows = 1000 32-row tiles = 3.9 rounds of the 256 CUs; the encoder's persistent kernels amortise over 640 clouds).
 DEFAULT_BATCHES_PER_LAUNCH = 10
 
