@@ -655,6 +655,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
     jn = load_idx(1);
     int gstep = 0;  // global ring step: slice gstep % Q2 sits in slot gstep % 3
     f32x4 wpre[4];  // first fragment group of the upcoming ring step
+    float res[Q3];  // running max of the pre-bias layer-3 output over the chunks of a neighbourhood, per channel 16 n + pt
 #pragma unroll
     for (int u = 0; u < 4; ++u) wpre[u] = ring[u * 64 + lane];
 #pragma unroll 1
@@ -741,12 +742,9 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
             // max_i relu(x_i + b) = relu(max_i x_i + b), so bias and ReLU come once per channel after the pooling
 #pragma unroll
             for (int n = 0; n < Q3; ++n) {
-                float m = fmaxf(points16_max_t(acc3[n]) + a.b3[16 * n + (lo & 15)], 0.f);
-                if (g == 0 && it < nits) {
-                    float *op = o + 16 * n + pt;
-                    if (p > 0) m = fmaxf(m, *op);  // later chunk of the same neighbourhood: combine with what this lane stored for the earlier one
-                    *op = m;
-                }
+                const float m = points16_max_t(acc3[n]);
+                res[n] = p == 0 ? m : fmaxf(res[n], m);  // running max over the neighbourhood's chunks: one register per chunk
+                if (p == PT - 1 && g == 0 && it < nits) o[16 * n + pt] = fmaxf(res[n] + a.b3[16 * n + (lo & 15)], 0.f);
             }
         }
     }
