@@ -248,36 +248,65 @@ class FullPipelinePredictor:
     score_agent / energy_agent : genpose_amd.posenet_agent.PoseNet with weights loaded (sampler_mode ['pc'] on the score agent)
     """
 
-    def __init__(self, score_agent, energy_agent, B, K, num_steps, ratio=0.6, T_energy=1e-5, overlap=True):
+    def __init__(self, score_agent, energy_agent, B, K, num_steps, ratio=0.6, T_energy=1e-5, overlap=True, batches_per_launch=1):
+        """batches_per_launch = G (run_many): G consecutive batches of B clouds share every encoder pass, the sampler launch chain
+        (each batch keeps its own batch-global coupling, gp_pc_step_grouped), the energy evaluation and the ranking launch - the
+        request batching of PipelinedPCPredictor applied to the whole pipeline.  At B = 256 one batch is 400 32-row tiles = 1.56 rounds
+        of the CUs (the second round 56 % full); five batches are 2000 tiles = 7.8 rounds."""
         _lib.check_device()
         self.snet, self.enet = score_agent.net, energy_agent.net
         self.snet._need_weights()
         self.enet._need_weights()
         if self.enet.cfg.posenet_mode != "energy" or self.snet.cfg.posenet_mode != "score":
             raise ValueError("FullPipelinePredictor(score_agent, energy_agent): agents in the wrong order / mode")
-        self.B, self.K, self.n, self.ratio = B, K, num_steps, ratio
+        self.B, self.K, self.n, self.ratio, self.G = B, K, num_steps, ratio, batches_per_launch
         self.dev = self.snet.device
         self.overlap = overlap
         self.share_grouping = self.snet.pts_encoder.grouping_key() == self.enet.pts_encoder.grouping_key()
         self.side = torch.cuda.Stream(self.dev, priority=0) if overlap else None
-        self.smp = PCSampler(self.snet.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False)
-        self.prior_host = torch.empty(B * K, 9).pin_memory()
-        self.x0 = torch.empty(B * K, 9, device=self.dev)
+        self._smp = {}
         self.ev_h2d = torch.cuda.Event()
         self.ev_h2d.record()
         self.ev_side = torch.cuda.Event()
+        R = self.G * B * K
+        self.prior_host = torch.empty(R, 9).pin_memory()
+        self.x0 = torch.empty(R, 9, device=self.dev)
+        self.pose_e = torch.empty(R, 9, device=self.dev)
         t = torch.full((1,), float(T_energy), device=self.dev)
         self.tvec_e = self.enet.pose_score_net.time_embed(t)[0].contiguous()
         self.sigma_e = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t).contiguous()
-        self.pose_e = torch.empty(B * K, 9, device=self.dev)
+
+    def _sampler(self, g):
+        if g not in self._smp:
+            self._smp[g] = PCSampler(self.snet.pose_score_net, g * self.B, self.K, self.n, self.dev, use_graph=True, record_traj=False, groups=g)
+        return self._smp[g]
 
     def run(self, pts, prior_noise=None, noise=None):
         """pts [B,1024,3] device tensor -> dict(pred_pose [B,K,9] f32, energy [B,K,2], sorted_poses, sorted_energy, order, avg_pose [B,7]).
         prior_noise (tests): standard-normal draws [B*K,9]; noise (tests): (z_langevin, z_predictor) [n,B*K,9]."""
+        if pts.shape[0] != self.B:
+            raise ValueError(f"predictor built for {self.B} clouds got {pts.shape[0]}")
+        return self._run_group(pts, 1, prior_noise, noise)
+
+    def run_many(self, batches, prior_noise=None, noise=None):
+        """batches: sequence of device tensors [B,1024,3] -> one result dict per batch (views into the launch group's tensors);
+        `batches_per_launch` of them share every launch.  prior_noise / noise (tests): per-batch draws as in run()."""
+        out = []
+        for i0 in range(0, len(batches), self.G):
+            grp = list(batches[i0:i0 + self.G])
+            g = len(grp)
+            pts = grp[0] if g == 1 else torch.cat(grp, dim=0)
+            pn = None if prior_noise is None else torch.cat([prior_noise[i0 + q].reshape(self.B * self.K, 9) for q in range(g)], dim=0)
+            nz = None if noise is None else (torch.cat([noise[i0 + q][0] for q in range(g)], dim=1), torch.cat([noise[i0 + q][1] for q in range(g)], dim=1))
+            res = self._run_group(pts, g, pn, nz)
+            for q in range(g):
+                sl = slice(q * self.B, (q + 1) * self.B)
+                out.append({k: (v[sl] if v is not None else None) for k, v in res.items()})
+        return out
+
+    def _run_group(self, pts, g, prior_noise, noise):
         from . import reward
-        B, K = self.B, self.K
-        if pts.shape[0] != B:
-            raise ValueError(f"predictor built for {B} clouds got {pts.shape[0]}")
+        B, K = g * self.B, self.K
         cur = torch.cuda.current_stream(self.dev)
         centre = pts.mean(dim=1)
         # ---- centres and neighbourhoods (furthest point sampling, ball queries) depend on the coordinates only: computed ONCE and
@@ -293,26 +322,29 @@ class FullPipelinePredictor:
             cvec_e.record_stream(cur)
         # ---- score model: encoder -> embedding -> prior -> the whole T-step loop as one graph replay
         cvec = self.snet.pose_score_net.cloud_embed(enc_s.forward(pts, grouping=grouping))
+        x0 = self.x0[: B * K]
         if prior_noise is None:
             self.ev_h2d.synchronize()
-            _randn_1t(self.prior_host)  # CPU generator, as sde.py:28
-            self.x0.copy_(self.prior_host, non_blocking=True)
+            host = self.prior_host[: B * K]
+            _randn_1t(host)  # CPU generator, as sde.py:28
+            x0.copy_(host, non_blocking=True)
             self.ev_h2d.record(cur)
         else:
-            self.x0.copy_(prior_noise.reshape(B * K, 9))
-        self.x0.mul_(SIGMA_MAX)
+            x0.copy_(prior_noise.reshape(B * K, 9))
+        x0.mul_(SIGMA_MAX)
         z1, z2 = noise if noise is not None else (None, None)
-        _, mean_x = self.smp.run(cvec, centre, self.x0, z1, z2)
+        _, mean_x = self._sampler(g).run(cvec, centre, x0, z1, z2)
         pred = mean_x.reshape(B, K, 9).clone()
         # ---- energy of every candidate (posenet_agent.py:471-527: translations relative to the cloud centre), ranking, aggregation
         if self.side is not None:
             cur.wait_event(self.ev_side)
         else:
             cvec_e = self.enet.pose_score_net.cloud_embed(enc_e.forward(pts, grouping=grouping))
-        pose = self.pose_e.view(B, K, 9)
+        pose_flat = self.pose_e[: B * K]
+        pose = pose_flat.view(B, K, 9)
         pose.copy_(pred)
         pose[:, :, 6:] -= centre.unsqueeze(1)
-        energy = self.enet.pose_score_net.evaluate(cvec_e, K, self.pose_e, self.tvec_e, self.sigma_e, "energy").reshape(B, K, 2)
+        energy = self.enet.pose_score_net.evaluate(cvec_e, K, pose_flat, self.tvec_e, self.sigma_e, "energy").reshape(B, K, 2)
         out = reward.rank_aggregate(pred, energy, ratio=self.ratio)
         out["pred_pose"], out["energy"] = pred, energy
         return out

@@ -207,3 +207,31 @@ def test_load_ckpt_through_a_pth_on_the_device(tmp_path):
     assert torch.equal(outs[0], outs[1])
     ref, _, _ = go.pred_func(sd, pts.cpu(), pts.cpu().mean(dim=1), 6, "pc", prior, sampling_steps=8, z_langevin=z[0].cpu(), z_predictor=z[1].cpu())
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+
+
+def test_full_pipeline_request_batching_keeps_every_batch():
+    """FullPipelinePredictor.run_many: G batches share every launch (encoders, sampler chain with per-batch coupling, energy evaluation,
+    ranking); every batch gets what run() gives it alone - up to the tile size of the sampler (32-row tiles for the group, 16-row for one
+    batch: the norm partials sum in a different order)."""
+    from genpose_amd import synth
+    from genpose_amd.pipeline import FullPipelinePredictor
+    B, K, n, G, NB = 64, 50, 20, 2, 3  # NB = 3 leaves a ragged tail (one batch alone in the last group)
+    sa, ea = make_agent("score", "pc", n), make_agent("energy")
+    batches = [torch.from_numpy(synth.make_batch(B, start=300 * i)).cuda() for i in range(NB)]
+    gen = torch.Generator().manual_seed(5)
+    priors = [torch.randn(B * K, 9, generator=gen).cuda() * (1.0 + i) for i in range(NB)]  # different scales: a launch-wide mean would show
+    noises = [(torch.randn(n, B * K, 9, generator=gen).cuda(), torch.randn(n, B * K, 9, generator=gen).cuda()) for _ in range(NB)]
+    fp = FullPipelinePredictor(sa, ea, B, K, n, batches_per_launch=G)
+    many = fp.run_many(batches, prior_noise=priors, noise=noises)
+    many = [{k: v.clone() for k, v in m.items()} for m in many]
+    assert len(many) == NB
+    for i in range(NB):
+        one = fp.run(batches[i], prior_noise=priors[i], noise=noises[i])
+        torch.cuda.synchronize()
+        assert many[i]["pred_pose"].shape == (B, K, 9) and many[i]["avg_pose"].shape == (B, 7)
+        scale = float(one["pred_pose"].abs().max())
+        np.testing.assert_allclose(many[i]["pred_pose"].cpu().numpy(), one["pred_pose"].cpu().numpy(), rtol=0, atol=1e-3 * scale, err_msg=f"batch {i}")
+        e1 = one["energy"].cpu().numpy()
+        np.testing.assert_allclose(many[i]["energy"].cpu().numpy(), e1, rtol=0, atol=2e-3 * np.abs(e1).max(), err_msg=f"batch {i}")
+        if i == NB - 1:  # the ragged tail runs alone, on the same 16-row tiles as run(): identical bits
+            assert torch.equal(many[i]["pred_pose"], one["pred_pose"]) and torch.equal(many[i]["order"], one["order"])
