@@ -31,7 +31,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_SCORE_ROW = 0.5335e6  # minimal ("hoisted") FLOPs per pose row per score evaluation
-FLOP_ENCODER = 2.201e9     # per cloud per encoder pass
+FLOP_ENCODER = 2.201e9     # per cloud per encoder pass, the reference's count (every first SA layer over the grouped [C+3] rows)
+
+
+def encoder_flops_executed():
+    """FLOPs the encoder EXECUTES per cloud after hoisting the feature half of every first SA layer: once per source
+    point instead of once per (centre, sample) row.  Light config (pointnet2.py:57-66)."""
+    levels = [  # (source points n, input channels, [(rows per cloud, c1, c2, c3) per scale])
+        (1024, 0, [(512 * 16, 16, 16, 32), (512 * 32, 32, 32, 64)]),
+        (512, 96, [(256 * 16, 64, 64, 128), (256 * 32, 64, 96, 128)]),
+        (256, 256, [(128 * 16, 128, 196, 256), (128 * 32, 128, 196, 256)]),
+        (128, 512, [(128, 256, 256, 512), (128, 256, 384, 512)]),
+    ]
+    tot = 0
+    for n, cin, scales in levels:
+        tot += 2 * n * cin * sum(c1 for _, c1, _, _ in scales)                      # hoisted feature half (point_linear / producer epilogue)
+        tot += sum(rows * 2 * (3 * c1 + c1 * c2 + c2 * c3) for rows, c1, c2, c3 in scales)  # xyz half + layers 2-3 per grouped row
+    return float(tot)
+
+
+FLOP_ENCODER_EXECUTED = encoder_flops_executed()  # 1.69e9
 FLOP_CLOUD_EMBED = 1.573e6
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # Request batching of the default run: consecutive 64-cloud batches that share one encoder pass and one sampler launch chain (each keeps
@@ -61,7 +80,7 @@ def parse():
     ap.add_argument("--no-fps-ahead", action="store_true", help="do not run furthest point sampling of the next launch group on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clouds", type=int, default=64, help="clouds of the CPU-baseline sample (BASELINE.md §3: one 64-cloud batch)")
-    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work the baseline leg may spend")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work the baseline leg may spend")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / ODE-100 side measurements")
     return ap.parse_args()
 
@@ -125,10 +144,14 @@ def main():
         energy_agent = PoseNet(get_config(device=str(dev), posenet_mode="energy"))
         energy_agent.load_state_dict(make_state_dict(0, "energy"))
 
-    # inputs resident in HBM before the timed region: this rank's B clouds (weak scaling: distinct clouds per rank)
-    pts = torch.from_numpy(synth.make_batch(B, start=rank * B)).to(dev)
+    # inputs resident in HBM before the timed region (weak scaling: distinct clouds per rank).  Every batch of a timed block is a
+    # DIFFERENT set of clouds (ball-query early exits are data dependent): a pool of `steps` batches, walked in order.
+    npool = max(1, args.steps)
+    pool = [torch.from_numpy(synth.make_batch(B, start=(rank * npool + j) * B)).to(dev) for j in range(npool)]
+    pts = pool[0]
     centre = pts.mean(dim=1)
     T0 = 0.55
+    batches_of = lambda count: [pool[j % npool] for j in range(count)]
 
     full_pred = None
     if energy_agent is not None and args.sampler == "pc" and not args.no_pipeline:
@@ -141,12 +164,12 @@ def main():
             outs = [torch.empty_like(o) for _ in range(world)]
             dist.all_gather(outs, o)
 
-    def step():
+    def step(pts=pts):
         if full_pred is not None:
             out = full_pred.run(pts)["avg_pose"]
             gather(out)
             return out
-        data = {"pts": pts, "pts_center": centre}
+        data = {"pts": pts, "pts_center": pts.mean(dim=1)}
         pred = score_agent.pred_func(data, repeat_num=K, save_path=None, T0=T0)
         out = pred
         if energy_agent is not None:
@@ -177,18 +200,18 @@ def main():
 
     def run_steps(count):
         if full_pred is not None:
-            for o in full_pred.run_many([pts] * count):
+            for o in full_pred.run_many(batches_of(count)):
                 gather(o["avg_pose"])
             return
         if ode_grouped:
-            for o in ode_pred.run([pts] * count):
+            for o in ode_pred.run(batches_of(count)):
                 gather(o)
             return
         if not pipelined:
-            for _ in range(count):
-                step()
+            for j in range(count):
+                step(pool[j % npool])
             return
-        for o in pipe.run([pts] * count):
+        for o in pipe.run(batches_of(count)):
             gather(o)
 
     step()  # builds samplers / captures graphs outside the timed region
@@ -244,17 +267,19 @@ def main():
     if rank == 0 and world == 1:
         # the same workload with ONE batch per launch (no request batching), reported next to the headline for comparison
         if pipelined and G > 1:
-            side["one_batch_per_launch"] = one_batch_leg(torch, score_agent, pts, B, K, n)
+            side["one_batch_per_launch"] = one_batch_leg(torch, score_agent, pool, B, K, n)
         if not args.no_secondary and args.pipeline == "score" and args.sampler == "pc" and not args.no_pipeline:
-            side["ode_100"] = ode_leg(torch, B, K, G, T0, pts, str(dev))
+            side["ode_100"] = ode_leg(torch, B, K, G, T0, pool, str(dev))
             side["full_pipeline_256"] = full_pipeline_leg(torch, K, n, str(dev))
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
     if rank == 0:
         flop_per_pose = FLOP_ENCODER + FLOP_CLOUD_EMBED + K * nfev * FLOP_SCORE_ROW
+        flop_exec = FLOP_ENCODER_EXECUTED + FLOP_CLOUD_EMBED + K * nfev * FLOP_SCORE_ROW
         if energy_agent is not None:
             flop_per_pose += FLOP_ENCODER + FLOP_CLOUD_EMBED + K * FLOP_SCORE_ROW
+            flop_exec += FLOP_ENCODER_EXECUTED + FLOP_CLOUD_EMBED + K * FLOP_SCORE_ROW
         line = {
             "metric": "poses/sec (1024-pt cloud, 50 cand x 100 SDE steps)", "value": round(value, 2), "unit": "poses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -269,7 +294,11 @@ def main():
                        "block_ms_min": round(times[0] * 1e3, 3), "block_ms_max": round(times[-1] * 1e3, 3), "statistic": "median block"},
             "launch": {"mode": os.environ.get("GP_BENCH_LAUNCH", "direct" if world == 1 else "torch.distributed.run"),
                        "world_size_observed": (dist.get_world_size() if dist is not None else 1), "backend": backend},
+            # whole_path_tflops credits the encoder with the reference's 2.201 GFLOP/cloud (SURVEY §8d's canonical figure);
+            # executed_tflops counts what the kernels actually execute (first SA layers hoisted: 1.69 GFLOP/cloud)
             "whole_path_tflops": round(value * flop_per_pose / 1e12, 2),
+            "executed_tflops": round(value * flop_exec / 1e12, 2),
+            "executed_frac_of_f32_mfma_peak": round(value * flop_exec / 1e12 / (world * PEAK_F32_MFMA_TFLOPS), 4),
             "gpu_event_ms_per_step": round(gpu_event_ms, 3),
             "roofline": roofline, "cpu_baseline": side.pop("cpu_baseline", None),
         }
@@ -331,14 +360,14 @@ def pc_roofline(torch, smp, rows, n):
     return roofline
 
 
-def one_batch_leg(torch, score_agent, pts, B, K, n):
+def one_batch_leg(torch, score_agent, pool, B, K, n):
     from genpose_amd.pipeline import PipelinedPCPredictor
     p1 = PipelinedPCPredictor(score_agent, B, K, n, batches_per_launch=1, overlap=False)
-    p1.run([pts] * 3)
+    p1.run(pool[:3])
     torch.cuda.synchronize()
     nb = 40
     t1 = time.perf_counter()
-    p1.run([pts] * nb)
+    p1.run([pool[j % len(pool)] for j in range(nb)])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
     r = pc_roofline(torch, p1._sampler(0, 1), B * K, n)
@@ -346,7 +375,7 @@ def one_batch_leg(torch, score_agent, pts, B, K, n):
             "rows_per_launch": B * K, "avg_launch_us": r["avg_launch_us"], "frac": r["frac"]}
 
 
-def ode_leg(torch, B, K, G, T0, pts, dev):
+def ode_leg(torch, B, K, G, T0, pool, dev):
     """Secondary mode ODE-100: cond_ode_sampler semantics, sampling_steps=100, T0=0.55, adaptive RK45 on the device."""
     from genpose_amd.config import get_config
     from genpose_amd.pipeline import GroupedODEPredictor
@@ -355,11 +384,11 @@ def ode_leg(torch, B, K, G, T0, pts, dev):
     agent = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=["ode"], sampling_steps=100))
     agent.load_state_dict(make_state_dict(0, "score"))
     pred = GroupedODEPredictor(agent, B, K, T0=T0, batches_per_launch=G)
-    pred.run([pts] * G)
+    pred.run([pool[j % len(pool)] for j in range(G)])
     torch.cuda.synchronize()
     nb = 4 * G
     t0 = time.perf_counter()
-    pred.run([pts] * nb)
+    pred.run([pool[j % len(pool)] for j in range(nb)])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nfev = int(round(sum(pred.last_nfev) / max(1, len(pred.last_nfev))))
@@ -378,36 +407,39 @@ def full_pipeline_leg(torch, K, n, dev, B=256):
     sa.load_state_dict(make_state_dict(0, "score"))
     ea = PoseNet(get_config(device=dev, posenet_mode="energy"))
     ea.load_state_dict(make_state_dict(0, "energy"))
-    pts = torch.from_numpy(synth.make_batch(B, start=4096)).to(dev)
-    G = 5  # batches of 256 clouds per launch chain (each with its own batch-global coupling)
+    G = 5  # batches of 256 clouds per launch chain (each with its own batch-global coupling): the shape tests/test_gpu_fullsize.py checks
+    pool = [torch.from_numpy(synth.make_batch(B, start=4096 + B * j)).to(dev) for j in range(G)]  # distinct clouds in every batch of a launch
+    pts = pool[0]
     fp = FullPipelinePredictor(sa, ea, B, K, n, batches_per_launch=G)
-    fp.run_many([pts] * G)
-    fp.run_many([pts] * G)
+    fp.run_many(pool)
+    fp.run_many(pool)
     torch.cuda.synchronize()
     nb = 3 * G
     t0 = time.perf_counter()
-    fp.run_many([pts] * nb)
+    fp.run_many([pool[j % G] for j in range(nb)])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     for _ in range(2):
         fp.run(pts)  # builds / captures the one-batch sampler outside the timing
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(6):
-        fp.run(pts)
+    for j in range(6):
+        fp.run(pool[j % G])
     torch.cuda.synchronize()
     dt1 = (time.perf_counter() - t1) / 6
     return {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "clouds": B, "batches_per_launch": G,
             "one_batch_per_launch": {"value": round(B / dt1, 2), "ms_per_step": round(dt1 * 1e3, 3)},
             "workload": f"{B} clouds x {K} cand: encoder + PC-{n} sampler (score model) | encoder + energy (energy model) -> ranking -> top-60% aggregate",
-            "flop_per_pose": 7.10e9, "whole_path_tflops": round(B * nb / dt * 7.10e9 / 1e12, 2)}
+            "flop_per_pose": 7.10e9, "whole_path_tflops": round(B * nb / dt * 7.10e9 / 1e12, 2),
+            "executed_tflops": round(B * nb / dt * (7.10e9 - 2 * (FLOP_ENCODER - FLOP_ENCODER_EXECUTED)) / 1e12, 2)}
 
 
 def run_cpu_baseline(torch, args, K, n):
     """The oracle (CPU restatement of the reference path, validated against the imported reference) timed on the host cores of this
     box on a bounded sample of the same workload: ONE batch of `--cpu-clouds` (64) clouds, as BASELINE.md §3 plans.  Checker
-    infrastructure used as a baseline: allowed use of oracle/ (task statement §3).  Thread counts 16/32/64/128 (<= cores) are tried
-    on the sampler; the best one runs the end-to-end (encoder + sampler) sample, which is what `value` reports."""
+    infrastructure used as a baseline: allowed use of oracle/ (task statement §3).  The two stages are swept over thread counts
+    SEPARATELY (the encoder is conv-like work over 12 MB of grouped rows per cloud, the sampler 100 small GEMMs over 3200 rows: their
+    optima differ), and the end-to-end sample (encoder + sampler, what `value` reports) runs each stage at ITS best count."""
     from genpose_amd import synth
     from oracle import genpose_oracle as go
     from oracle import pn2_oracle as ops
@@ -423,56 +455,63 @@ def run_cpu_baseline(torch, args, K, n):
     if args.sampler == "pc":
         z1, z2 = torch.randn(n, Bc * K, 9, generator=gen), torch.randn(n, Bc * K, 9, generator=gen)
     ncores = os.cpu_count() or 1
-    cands = [t for t in (16, 32, 64, 128) if t <= ncores] or [ncores]
+    cands = [t for t in (8, 16, 32, 64, 128, 256) if t <= ncores] or [ncores]
     saved = torch.get_num_threads()
+    cen_r = cen.repeat_interleave(K, 0)
 
     def set_threads(t):
         torch.set_num_threads(t)
         ops.opt_n_threads(t)
 
-    def sampler_only(feat_r, cen_r):
+    def encoder(threads):
+        set_threads(threads)
+        return go.encoder_forward(sd, pts)
+
+    def sampler(threads, feat):
+        set_threads(threads)
+        feat_r = feat.repeat_interleave(K, 0)
         fn = lambda x, t: go.score_forward(sd, feat_r, x, t)
         if args.sampler == "pc":
-            go.pc_sampler(fn, prior * 50.0, cen_r, n, z1, z2)
+            go.pc_sampler(fn, prior * float(go.ve_sigma(1.0)), cen_r, n, z1, z2)
         else:
             go.ode_sampler(fn, prior * float(go.ve_sigma(torch.tensor(0.55))), cen_r, 0.55)
 
-    def end_to_end():
-        if args.sampler == "pc":
-            go.pred_func(sd, pts, cen, K, "pc", prior, sampling_steps=n, z_langevin=z1, z_predictor=z2)
-        else:
-            go.pred_func(sd, pts, cen, K, "ode", prior, T0=0.55)
+    def sweep(fn, share):
+        """Seconds per thread count, ascending; stops once a count is 1.3x slower than the best so far or the stage's share of the
+        budget is spent."""
+        t_in, out = time.perf_counter(), {}
+        for t in cands:
+            t0 = time.perf_counter()
+            fn(t)
+            out[t] = time.perf_counter() - t0
+            if out[t] > 1.3 * min(out.values()) or time.perf_counter() - t_in > share * budget:
+                break
+        return out
 
     try:
-        set_threads(cands[-1])
+        set_threads(min(16, ncores))
         go.pred_func(sd, pts[:2], cen[:2], 2, "pc", prior[:4], sampling_steps=2, z_langevin=torch.zeros(2, 4, 9), z_predictor=torch.zeros(2, 4, 9))  # library init
-        feat = go.encoder_forward(sd, pts[:8]).repeat(Bc // 8 + 1, 1)[:Bc]  # any features do for the sampler-only timing
-        feat_r, cen_r = feat.repeat_interleave(K, 0), cen.repeat_interleave(K, 0)
-        tried = {}
-        for t in cands:
-            if time.perf_counter() - t_start > 0.45 * budget and tried:
-                break
-            set_threads(t)
-            t0 = time.perf_counter()
-            sampler_only(feat_r, cen_r)
-            tried[t] = round(Bc / (time.perf_counter() - t0), 2)
-        best = max(tried, key=tried.get)
-        set_threads(best)
+        feat = encoder(min(16, ncores))  # warm (page-in, thread pools); its features feed the sampler sweep
+        enc_s = sweep(encoder, 0.3)
+        smp_s = sweep(lambda t: sampler(t, feat), 0.3)
+        best_enc, best_smp = min(enc_s, key=enc_s.get), min(smp_s, key=smp_s.get)
         runs = []
         while True:
             t0 = time.perf_counter()
-            end_to_end()
+            sampler(best_smp, encoder(best_enc))
             runs.append(time.perf_counter() - t0)
             if time.perf_counter() - t_start + runs[-1] > budget or len(runs) >= 10:
                 break
     finally:
         set_threads(saved)
     med = statistics.median(runs)
-    return {"value": round(Bc / med, 3), "unit": "poses/s", "cores": best, "kind": "port", "host_cores": ncores,
-            "sampler_only_poses_per_s_by_threads": tried, "end_to_end_runs_s": [round(r, 2) for r in runs],
-            "sample": f"{len(runs)} x ({Bc} clouds x 1024 pts, {K} cand, {args.sampler.upper()} {n} steps), encoder + sampler end to end, median, "
-                      f"{best} threads (best of {sorted(tried)} on the sampler); {time.perf_counter() - t_start:.1f} s of CPU work in total; "
-                      "oracle/genpose_oracle.py (torch-CPU fp32 MLPs + OpenMP C ops)"}
+    return {"value": round(Bc / med, 3), "unit": "poses/s", "cores": max(best_enc, best_smp), "kind": "port", "host_cores": ncores,
+            "threads": {"encoder": best_enc, "sampler": best_smp},
+            "encoder_s_by_threads": {t: round(v, 3) for t, v in enc_s.items()}, "sampler_s_by_threads": {t: round(v, 3) for t, v in smp_s.items()},
+            "end_to_end_runs_s": [round(r, 2) for r in runs],
+            "sample": f"{len(runs)} x ({Bc} clouds x 1024 pts, {K} cand, {args.sampler.upper()} {n} steps), encoder + sampler end to end, median; "
+                      f"each stage at its own best thread count (encoder {best_enc}, sampler {best_smp}; swept {sorted(set(enc_s) | set(smp_s))}); "
+                      f"{time.perf_counter() - t_start:.1f} s of CPU work in total; oracle/genpose_oracle.py (torch-CPU fp32 MLPs + OpenMP C ops)"}
 
 
 if __name__ == "__main__":

@@ -235,3 +235,66 @@ def test_full_pipeline_request_batching_keeps_every_batch():
         np.testing.assert_allclose(many[i]["energy"].cpu().numpy(), e1, rtol=0, atol=2e-3 * np.abs(e1).max(), err_msg=f"batch {i}")
         if i == NB - 1:  # the ragged tail runs alone, on the same 16-row tiles as run(): identical bits
             assert torch.equal(many[i]["pred_pose"], one["pred_pose"]) and torch.equal(many[i]["order"], one["order"])
+
+
+def test_config2_run_many_as_timed():
+    """BASELINE configs[2] exactly as bench.py's `full_pipeline_256` leg times it: FullPipelinePredictor.run_many with FIVE batches of 256
+    clouds per launch (64 000 rows, 2000 32-row tiles), K = 50, 100 PC steps, distinct clouds in every batch, injected draws.  Every batch
+    must be what run() gives it alone; the ranking must be the exact stable permutation on all 1 280 clouds; one batch goes against the
+    CPU oracle (sampler over its 12 800 coupled rows; energies and aggregation on a slice)."""
+    from genpose_amd import synth
+    from genpose_amd.pipeline import FullPipelinePredictor
+    B, K, n, G = 256, 50, 100, 5
+    R = B * K
+    sa, ea = make_agent("score", "pc", n), make_agent("energy")
+    batches = [torch.from_numpy(synth.make_batch(B, start=20000 + B * i)).cuda() for i in range(G)]
+    gen = torch.Generator().manual_seed(404)
+    priors = [torch.randn(R, 9, generator=gen) for _ in range(G)]
+    noises = [(torch.randn(n, R, 9, generator=gen), torch.randn(n, R, 9, generator=gen)) for _ in range(G)]
+    priors_dev = [p.cuda() for p in priors]
+    noises_dev = [(a.cuda(), b.cuda()) for a, b in noises]
+    fp = FullPipelinePredictor(sa, ea, B, K, n, batches_per_launch=G)
+    assert fp._sampler(G).tile == 32 and fp._sampler(G).R == G * R
+    many = [{k: v.clone() for k, v in m.items()} for m in fp.run_many(batches, prior_noise=priors_dev, noise=noises_dev)]
+    torch.cuda.synchronize()
+    assert len(many) == G
+    for i, m in enumerate(many):
+        assert m["pred_pose"].shape == (B, K, 9) and m["energy"].shape == (B, K, 2) and m["avg_pose"].shape == (B, 7)
+        _check_pose_properties(m["pred_pose"])
+        assert torch.isfinite(m["energy"]).all() and torch.isfinite(m["avg_pose"]).all()
+        # exact (stable, descending) permutation of THIS batch's energies, on every one of its 256 clouds
+        e_cpu, order = m["energy"].cpu(), m["order"].cpu().long()
+        for c in range(2):
+            ref = torch.sort(e_cpu[:, :, c], dim=1, descending=True, stable=True)
+            assert torch.equal(order[:, :, c], ref.indices), (i, c)
+            assert torch.equal(m["sorted_energy"][:, :, c].cpu(), ref.values)
+        bi = torch.arange(B).unsqueeze(1).expand(B, K)
+        p_cpu = m["pred_pose"].cpu()
+        want = p_cpu[bi, order[:, :, 0]].clone()
+        want[:, :, 6:] = p_cpu[bi, order[:, :, 1]][:, :, 6:]
+        assert torch.equal(m["sorted_poses"].cpu(), want)
+        # == the batch alone (same 32-row tiles, its own launch chain): the coupling stays per batch
+        one = fp.run(batches[i], prior_noise=priors_dev[i], noise=noises_dev[i])
+        torch.cuda.synchronize()
+        _assert_pc100_close(p_cpu.numpy(), one["pred_pose"].cpu().numpy(), f"configs[2] run_many batch {i} vs run() alone")
+        e1 = one["energy"].cpu().numpy()
+        np.testing.assert_allclose(e_cpu.numpy(), e1, rtol=0, atol=2e-3 * np.abs(e1).max(), err_msg=f"batch {i}")
+    # a second replay gives the same bits
+    again = fp.run_many(batches, prior_noise=priors_dev, noise=noises_dev)
+    torch.cuda.synchronize()
+    for a, b in zip(again, many):
+        assert torch.equal(a["pred_pose"], b["pred_pose"]) and torch.equal(a["order"], b["order"]) and torch.equal(a["avg_pose"], b["avg_pose"])
+    # batch 3 against the oracle
+    i = 3
+    m = many[i]
+    pts_cpu = batches[i].cpu()
+    ref_pred = _oracle_pc(go.make_state_dict(0, "score"), pts_cpu, K, priors[i], n, noises[i][0], noises[i][1])
+    _assert_pc100_close(m["pred_pose"].cpu().numpy(), ref_pred.numpy(), f"configs[2] run_many batch {i} (12800 of 64000 rows x 100 steps) vs oracle")
+    sl = slice(40, 56)
+    cen = pts_cpu.mean(dim=1)
+    ref_e = go.get_energy(go.make_state_dict(0, "energy"), pts_cpu[sl], cen[sl], m["pred_pose"][sl].cpu(), T=1e-5).numpy()
+    np.testing.assert_allclose(m["energy"][sl].cpu().numpy(), ref_e, rtol=5e-4, atol=5e-4 * np.abs(ref_e).max())
+    _, qt = go.aggregate_sorted(go.pose9_to_RT(m["sorted_poses"][sl].cpu()), ratio=0.6)
+    avg = m["avg_pose"][sl].cpu().numpy()
+    np.testing.assert_allclose(avg[:, 4:], qt.numpy()[:, 4:], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(qt.numpy()[:, 4:]).max())))
+    assert np.all(np.abs(np.sum(avg[:, :4] * qt.numpy()[:, :4], axis=1)) > 1 - 1e-5)
