@@ -9,12 +9,17 @@ forward(pts [B,N,3] f32 on the GPU) -> [B,1024].  Launch sequence per call (all 
 Intermediate features stay point-major [B, n, C]; the reference's grouped [B,C+3,np,ns] tensors never exist.
 """
 import ctypes
+import itertools
+import weakref
 
 import torch
 
 from . import _lib
 from ._lib import ptr, stream_ptr
 from .weights import EncoderWeights
+
+
+_GENERATION = itertools.count(1)  # process-wide: every write of a workspace's grouping buffers gets a generation no other write has
 
 
 class Pointnet2EncoderHIP:
@@ -62,6 +67,7 @@ class Pointnet2EncoderHIP:
         xyz0 = pts[..., 0:3].contiguous()
         B, N, _ = xyz0.shape
         ws = self._workspace(B, N, slot)
+        ws["_gen"] = next(_GENERATION)  # fps_idx / new_xyz are about to be overwritten: tickets for the previous contents die here
         st = stream_ptr()
         cfg = self.cfg
         group_levels = [k for k, npnt in enumerate(cfg["npoints"]) if npnt is not None]
@@ -82,6 +88,7 @@ class Pointnet2EncoderHIP:
 
     def _ball_queries(self, ws, xyz0, B, N):
         """Ball queries of every grouping level (they depend on the coordinates only) into ws['bq']."""
+        ws["_gen"] = next(_GENERATION)  # every writer of the grouping buffers invalidates outstanding tickets
         st = stream_ptr()
         cfg = self.cfg
         xyz, n = xyz0, N
@@ -113,18 +120,19 @@ class Pointnet2EncoderHIP:
         ws = self._workspace(B, N, slot)
         self._ball_queries(ws, xyz0, B, N)
         ws["_grouping_key"] = self.grouping_key()
-        ws["_gen"] = ws.get("_gen", 0) + 1
         return ws
 
     def grouping_ticket(self, pts, ws):
-        """What a second encoder needs to take this grouping over safely (GFObjectPose.extract_pts_feature): which clouds it belongs
-        to and which generation of the workspace it is (the workspace is overwritten by the next call)."""
-        return {"ws": ws, "gen": ws["_gen"], "key": self.grouping_key(), "ptr": pts.data_ptr(), "shape": tuple(pts.shape)}
+        """What a second encoder needs to take this grouping over safely (GFObjectPose.extract_pts_feature): WHICH tensor object the
+        clouds are (a weak reference - an address can be reused by the allocator, an object cannot), which version of it (in-place
+        edits bump `_version`), and which generation of the workspace (every writer of the grouping buffers - prepare_grouping, a plain
+        forward(), sample_centres - takes a fresh process-wide generation, so a ticket never outlives the contents it was issued for)."""
+        return {"ws": ws, "gen": ws["_gen"], "key": self.grouping_key(), "pts": weakref.ref(pts), "version": pts._version, "shape": tuple(pts.shape)}
 
     @staticmethod
     def ticket_valid(ticket, pts, key):
-        return (ticket is not None and ticket["key"] == key and ticket["ptr"] == pts.data_ptr() and ticket["shape"] == tuple(pts.shape)
-                and ticket["ws"].get("_gen") == ticket["gen"])
+        return (ticket is not None and ticket["key"] == key and ticket["pts"]() is pts and ticket["version"] == pts._version
+                and ticket["shape"] == tuple(pts.shape) and ticket["ws"].get("_gen") == ticket["gen"])
 
     def forward(self, pts, return_intermediates=False, slot=0, centres_done=False, grouping=None):
         """grouping: workspace returned by prepare_grouping() of an encoder with the same grouping configuration, for the SAME

@@ -122,13 +122,14 @@ class GFObjectPose:
             if n is None:
                 raise ValueError("the PC sampler needs cfg.sampling_steps")
             x0 = self._prior_to_device((R, 9)) if init_x is None else init_x.float()
-            key = ("pc", B, K, n, return_process)
+            coupling = getattr(self, "coupling_group", None)
+            key = ("pc", B, K, n, return_process, id(coupling) if coupling is not None else None)  # a coupled sampler is a different sampler
             smp = self._samplers.get(key)
             if smp is None:
                 # self.coupling_group (optional, set by the caller): the batch is sharded over the ranks of that process group and
                 # the Langevin step size is taken over ALL of its rows (PCSampler, "faithful" multi-GPU mode)
                 smp = self._samplers[key] = PCSampler(self.pose_score_net, B, K, n, self.device, record_traj=return_process,
-                                                      coupling_group=getattr(self, "coupling_group", None))
+                                                      coupling_group=coupling)
             z1, z2 = noise if noise is not None else (None, None)
             xs, res = smp.run(cvec, centre, x0, z1, z2)
             return (xs.clone() if xs is not None else None), res.clone()
@@ -185,7 +186,7 @@ class GFObjectPose:
         """The hoisted time embedding serves ONE diffusion time per launch: refuse per-row times instead of silently using row 0
         (they only occur in training and in get_energy(T=None), which groups the rows by time itself)."""
         tt = t.reshape(-1)
-        if trusted:
+        if trusted or (tt.is_cuda and torch.cuda.is_current_stream_capturing()):  # the check reads the device: not inside a capture
             return tt[:1].float().contiguous()
         if tt.numel() > 1 and not bool((tt == tt[0]).all()):
             raise NotImplementedError("per-row diffusion times: the HIP path evaluates one time value per launch (uniform t)")

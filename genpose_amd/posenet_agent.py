@@ -15,7 +15,7 @@ import torch
 
 from . import rotation
 from .posenet import GFObjectPose
-from .sde import init_sde
+from .sde import SIGMA_MAX, SIGMA_MIN, init_sde
 
 
 class PoseNet:
@@ -109,13 +109,19 @@ class PoseNet:
                 rows["t"] = torch.ones(bs * repeat_num, 1).type_as(pts_feat) * T
                 return self.net(rows, mode="energy").reshape(bs, repeat_num, -1)
             # posenet_agent.py:504-509: one random T per cloud from {1e-5, 2e-5, ..., 9e-5} (torch.randint(1, 10)/1e5, drawn on
-            # the CPU generator).  The kernels serve one time value per launch, so the launch is repeated per DISTINCT value (at
-            # most nine) and every cloud keeps the result of its own T.
-            T_samples = torch.randint(int(1e-5 * 1e5), int(1e-4 * 1e5), (bs, 1)).type_as(pts_feat) / 1e5
-            self.last_T_samples = T_samples
+            # the CPU generator).  The kernels serve one time value per launch, so the clouds are grouped by their T: one launch per
+            # DISTINCT value (at most nine) over THAT value's clouds only - every row is evaluated exactly once.
+            T_int = torch.randint(int(1e-5 * 1e5), int(1e-4 * 1e5), (bs, 1))
+            self.last_T_samples = T_dev = T_int.type_as(pts_feat) / 1e5  # divided on the device, like the reference (.type_as comes first)
+            psn = self.net.pose_score_net
+            cvec = psn.cloud_embed(pts_feat.float())
+            pose3 = pose.view(bs, repeat_num, -1)
             energy = torch.empty(bs, repeat_num, 2, device=pts_feat.device, dtype=torch.float32)
-            for tv in torch.unique(T_samples.cpu()).tolist():
-                rows["t"] = torch.ones(bs * repeat_num, 1).type_as(pts_feat) * tv
-                e = self.net(rows, mode="energy").reshape(bs, repeat_num, -1)
-                energy = torch.where((T_samples == tv).reshape(bs, 1, 1), e, energy)
+            for tv in torch.unique(T_int).tolist():
+                idx = torch.nonzero(T_int.reshape(-1) == tv).reshape(-1).to(pts_feat.device)
+                t0 = T_dev.reshape(-1)[idx[:1]].float().contiguous()  # this group's time value, as the device computed it
+                sigma = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t0).contiguous()
+                e = psn.evaluate(cvec.index_select(0, idx).contiguous(), repeat_num, pose3.index_select(0, idx).reshape(-1, pose3.shape[-1]).contiguous(),
+                                 psn.time_embed(t0)[0], sigma, "energy")
+                energy.index_copy_(0, idx, e.reshape(idx.numel(), repeat_num, 2))
             return energy

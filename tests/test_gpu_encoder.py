@@ -60,3 +60,49 @@ def test_energy_weights_encoder(golden):
     ref = go.encoder_forward(sde, pts).numpy()
     got = Pointnet2EncoderHIP(sde, "cuda").forward(pts.cuda()).cpu().numpy()
     np.testing.assert_allclose(got, ref, rtol=ENC_RTOL, atol=ENC_ATOL)
+
+
+def test_grouping_ticket_dies_with_the_workspace_contents():
+    """The score agent leaves a ticket for its centres / neighbourhoods in the data dict; the energy agent honours it only while the
+    workspace still holds THAT grouping for THAT tensor.  Every writer of the grouping buffers (a plain forward of another cloud batch of the
+    same shape, sample_centres) and every in-place edit of the clouds must invalidate it - otherwise the energy encoder would silently run
+    with another cloud's centres."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    sa = PoseNet(get_config(posenet_mode="score", sampler_mode=["pc"], sampling_steps=4))
+    sa.load_state_dict(go.make_state_dict(0, "score"))
+    ea = PoseNet(get_config(posenet_mode="energy"))
+    ea.load_state_dict(go.make_state_dict(0, "energy"))
+    B, K = 4, 5
+    pts = torch.from_numpy(synth.make_batch(B, start=900)).cuda()
+    other = torch.from_numpy(synth.make_batch(B, start=950)).cuda()
+    poses = torch.randn(B, K, 9, generator=torch.Generator().manual_seed(0)).cuda()
+    want = ea.get_energy({"pts": pts, "pts_center": pts.mean(dim=1)}, poses, T=1e-5).clone()  # fresh dict: no ticket, own grouping
+    enc_s, enc_e = sa.net.pts_encoder, ea.net.pts_encoder
+
+    def ticketed():
+        data = {"pts": pts, "pts_center": pts.mean(dim=1)}
+        sa.pred_func(data, K, save_path=None)
+        assert enc_e.ticket_valid(data["_grouping"], pts, enc_e.grouping_key())
+        return data
+
+    # the intended use: same dict, same tensor, workspace untouched -> taken over, same bits
+    data = ticketed()
+    assert torch.equal(ea.get_energy(data, poses, T=1e-5), want)
+    # a plain forward of OTHER clouds of the same shape overwrites the workspace -> the ticket is dead, the result is still right
+    data = ticketed()
+    enc_s(other)
+    assert not enc_e.ticket_valid(data["_grouping"], pts, enc_e.grouping_key())
+    assert torch.equal(ea.get_energy(data, poses, T=1e-5), want)
+    # so does sample_centres alone
+    data = ticketed()
+    enc_s.sample_centres(other)
+    assert not enc_e.ticket_valid(data["_grouping"], pts, enc_e.grouping_key())
+    assert torch.equal(ea.get_energy(data, poses, T=1e-5), want)
+    # an in-place edit of the clouds, and a different tensor object holding the same values
+    data = ticketed()
+    pts.add_(0.0)
+    assert not enc_e.ticket_valid(data["_grouping"], pts, enc_e.grouping_key())
+    data = ticketed()
+    assert not enc_e.ticket_valid(data["_grouping"], pts.clone(), enc_e.grouping_key())
