@@ -338,7 +338,7 @@ def pc_roofline(torch, smp, rows, n):
     per_launch_s = (chain_s - fin_s) / n
     flops_per_launch = rows * FLOP_SCORE_ROW
     ach = flops_per_launch / per_launch_s / 1e12
-    roofline = {"bound": "mfma", "kernel": f"pc_step_kernel<{smp.tile}>", "rows_per_launch": rows, "achieved": round(ach, 2),
+    roofline = {"bound": "mfma", "kernel": smp.kernel_name, "rows_per_launch": rows, "achieved": round(ach, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                 "avg_launch_us": round(per_launch_s * 1e6, 2), "finish_launch_us": round(fin_s * 1e6, 2), "full_launches_per_chain": n,
                 "flops_per_launch": flops_per_launch}

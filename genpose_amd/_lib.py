@@ -52,6 +52,9 @@ SIGNATURES = {
     "gp_score_div": [c_int, c_int, NETP, P, P, P, P, P, P, P, P],
     "gp_energy_score": [c_int, c_int, NETP, P, P, P, P, P, P, P],
     "gp_pc_tile_rows": [c_int, c_int, c_int],
+    "gp_pc_layout": [c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
+    "gp_pc_step_plan": [c_int, c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 12 + [P],
+    "gp_score_eval_plan": [c_int, c_int, c_int, NETP, P, P, P, P, c_int, P, P],
     "gp_pc_step_grouped": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
     "gp_pc_step_coupled": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 12 + [P],
     "gp_rk45_state_bytes": [],

@@ -18,9 +18,6 @@ SO = os.path.join(LIBDIR, f"libgenpose_hip_{TAG}.so" if TAG else "libgenpose_hip
 OBJDIR = os.path.join(LIBDIR, f"obj_{TAG}") if TAG else LIBDIR
 SOURCES = ["misc.hip", "pn2_ops.hip", "sa_mlp.hip", "scorenet.hip", "rk45.hip", "rank.hip", "preprocess.hip", "score_div.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
-TIMING = bool(os.environ.get("GP_TIMING"))  # tuning build: phase timestamps (needs relocatable device code)
-if TIMING:
-    FLAGS += ["-DGP_TIMING", "-fgpu-rdc"]
 FLAGS += [f for f in os.environ.get("GP_EXTRA_FLAGS", "").split() if f]
 
 
@@ -56,7 +53,7 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
-    cmd = [_hipcc(), "--offload-arch=gfx950"] + (["-fgpu-rdc", "--hip-link"] if TIMING else []) + ["-shared", "-fPIC", "-o", SO] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
     subprocess.check_call(cmd)
     return SO
 

@@ -12,48 +12,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Keeps an early-requested value where it was requested: without it hipcc sinks the load next to its first use.
 __device__ __forceinline__ void gp_pin(float &v) { asm volatile("" : "+v"(v)); }
 
-// Phase timestamps for tuning builds (python -m genpose_amd.build with GP_TIMING=1): block 0, lane 0 of every wave.
-// The stamps stay in registers (struct GpStamps, carried in the trunk's TrunkPre) and are written out once at the end
-// of the kernel: a store per stamp would put an s_waitcnt lgkmcnt(0) - i.e. a drain of all LDS traffic - at every phase edge.
-#ifdef GP_TIMING
-extern __device__ unsigned long long gp_dbg_ts[8 * 32];
-extern __device__ unsigned long long gp_dbg_wg[1024 * 4];  // per workgroup: HW_ID, XCC_ID, start, end (occupancy studies)
-#define GP_WG_BEGIN() const unsigned long long gp_wg_t0_ = __builtin_amdgcn_s_memtime()
-#define GP_WG_END()                                                                                     \
-    do {                                                                                                \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                    \
-            gp_dbg_wg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    \
-            gp_dbg_wg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   \
-            gp_dbg_wg[blockIdx.x * 4 + 2] = gp_wg_t0_;                                                  \
-            gp_dbg_wg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();                               \
-        }                                                                                               \
-    } while (0)
-struct GpStamps {
-    unsigned long long t[24];
-};
-#define GP_T(i) (pre.ts.t[(i)] = __builtin_amdgcn_s_memtime())
-#define GP_T_FLUSH()                                                                          \
-    do {                                                                                      \
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                     \
-            _Pragma("unroll") for (int q_ = 0; q_ < 24; ++q_) gp_dbg_ts[(threadIdx.x >> 6) * 32 + q_] = pre.ts.t[q_]; \
-        }                                                                                     \
-    } while (0)
-#else
-#define GP_WG_BEGIN() \
-    do {              \
-    } while (0)
-#define GP_WG_END() \
-    do {            \
-    } while (0)
-struct GpStamps {};
-#define GP_T(i) \
-    do {        \
-    } while (0)
-#define GP_T_FLUSH() \
-    do {             \
-    } while (0)
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // fp32 MFMA building block: Y^T[N, P] = W[N, K] . X^T[K, P]  on v_mfma_f32_16x16x4_f32
 // (exact f32: bitwise a k-ordered fmaf chain, 157 TFLOP/s chip peak - MI355X_MICROARCH.md).
@@ -83,10 +41,7 @@ __host__ __device__ static inline int gp_round16(int v) { return (v + 15) & ~15;
 // register rotation copies are needed, and sched_barrier keeps the requests ABOVE the MFMA block (hipcc otherwise
 // sinks loads next to their first use and the counted s_waitcnt degenerates to vmcnt(0)).
 // mfma_preload() may be issued EARLY (before the producing layer's epilogue / barrier) to hide the cold start.
-#ifndef GP_MFMA_STAGES
-#define GP_MFMA_STAGES 3  // register stages of the weight/activation pipeline (prefetch distance = stages - 1 k-groups)
-#endif
-constexpr int MST = GP_MFMA_STAGES;
+constexpr int MST = 3;  // register stages of the weight/activation pipeline (prefetch distance = stages - 1 k-groups); 4 and 5 measured slower
 
 template <int NV>
 struct WStages {
@@ -115,10 +70,8 @@ __device__ __forceinline__ void mfma_step(WStages<NV> &st, f32x4 (&xq)[MST][PT],
                                           size_t kstride, int kgd, int KG, f32x4 (&acc)[4][PT]) {
     const int nxt = (kgd + MST - 1 < KG) ? kgd + MST - 1 : KG - 1;
     constexpr int e = (D + MST - 1) % MST;
-#ifndef GP_EXP_NOWLOAD
 #pragma unroll
     for (int i = 0; i < NV; ++i) st.w[e][i] = wp[i][(size_t)nxt * kstride];
-#endif
 #pragma unroll
     for (int p = 0; p < PT; ++p) xq[e][p] = *reinterpret_cast<const f32x4 *>(xrow[p] + nxt * 16);
     __builtin_amdgcn_sched_barrier(0);

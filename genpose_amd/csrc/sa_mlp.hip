@@ -7,8 +7,6 @@
 //   gather rows into LDS  [P][K0pad+8]   (feature columns first, then dx,dy,dz, zero pad)
 //   layer 1: LDS A -> LDS B,  layer 2: LDS B -> LDS A,  layer 3: LDS A -> registers -> max -> global.
 // Weights stream from L2 straight into MFMA A-operand registers (host-packed fragment order, gp_common.h).
-#include <stdlib.h>
-
 #include "gp_common.h"
 
 namespace {
@@ -571,12 +569,7 @@ int launch_chain_lds(const SAPreArgs &a, int b, hipStream_t st) {
         done = true;
     }
     const int ncentres = b * a.np;
-    static int forced_pc = -1;  // GP_SA_CHAIN_PER_CU = 1 | 2 (tuning)
-    if (forced_pc < 0) {
-        const char *e = getenv("GP_SA_CHAIN_PER_CU");
-        forced_pc = e ? atoi(e) : 0;
-    }
-    const int per_cu = forced_pc > 0 ? forced_pc : ((int)((160 * 1024) / lds) < 2 ? 1 : 2);
+    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;
     int blocks = (ncentres + 3) / 4;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // persistent: weights are staged once per workgroup
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a, ncentres);
@@ -819,17 +812,12 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
              groupall ? 1 : 0};
     hipStream_t st = (hipStream_t)s;
     if (!groupall && ns > 64) return GP_EINVAL;
-    static int forced = -1;  // GP_SA_P = 32 | 64 (tuning override)
-    if (forced < 0) {
-        const char *e = getenv("GP_SA_P");
-        forced = e ? atoi(e) : 0;
-    }
     // 32-row tiles keep 2-3 workgroups per CU resident (gather of one overlaps the MFMA phase of another); measured
     // faster than 64-row tiles on every level of the light config.  ns = 64 needs 64 rows (one wave owns a neighbourhood).
     // Narrow levels (all widths <= 64: SA level 0) are overhead-bound, not MFMA-bound: 64-row tiles halve the per-tile
     // fixed cost (measured 274 vs 382 us at B = 64).
     const bool narrow = c1 <= 64 && c2 <= 64 && c3 <= 64;
-    if (groupall || (ns <= 32 && forced != 64 && !(narrow && forced != 32))) return launch<32>(a, b, st);
+    if (groupall || (ns <= 32 && !narrow)) return launch<32>(a, b, st);
     if (lds_bytes(64, a) <= 150 * 1024) return launch<64>(a, b, st);
     return GP_EINVAL;
 }
@@ -867,19 +855,15 @@ int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, cons
     SAPreArgs a{n, np, ns, c1, c2, c3, zstride, zoff, xyz, new_xyz, z, idx, wxyz, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off,
                 groupall ? 1 : 0};
     if (groupall) return launch_pre<32>(a, b, (hipStream_t)s);
-    static int nochain = -1;  // GP_SA_NOCHAIN=1 forces the tile kernel (tuning / A-B tests)
-    if (nochain < 0) nochain = getenv("GP_SA_NOCHAIN") ? 1 : 0;
-    if (!z && !nochain) {
+    if (!z) {
         if (c1 == 16 && c2 == 16 && c3 == 32 && ns == 16) return launch_chain<16, 16, 32, 16>(a, b, (hipStream_t)s);
         if (c1 == 32 && c2 == 32 && c3 == 64 && ns == 32) return launch_chain<32, 32, 64, 32>(a, b, (hipStream_t)s);
     }
-    if (z && !nochain && (zoff % 4) == 0 && (zstride % 4) == 0) {
+    if (z && (zoff % 4) == 0 && (zstride % 4) == 0) {
         if (c1 == 64 && c2 == 64 && c3 == 128 && ns == 16) return launch_chain_lds<64, 64, 128, 16>(a, b, (hipStream_t)s);
         if (c1 == 64 && c2 == 96 && c3 == 128 && ns == 32) return launch_chain_lds<64, 96, 128, 32>(a, b, (hipStream_t)s);
-        static int noring = -1;
-        if (noring < 0) noring = getenv("GP_SA_NORING") ? 1 : 0;
-        if (!noring && c1 == 128 && c2 == 196 && c3 == 256 && ns == 16) return launch_chain_ring<128, 196, 256, 16>(a, b, (hipStream_t)s);
-        if (!noring && c1 == 128 && c2 == 196 && c3 == 256 && ns == 32) return launch_chain_ring<128, 196, 256, 32>(a, b, (hipStream_t)s);
+        if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 16) return launch_chain_ring<128, 196, 256, 16>(a, b, (hipStream_t)s);
+        if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 32) return launch_chain_ring<128, 196, 256, 32>(a, b, (hipStream_t)s);
     }
     const bool narrow = c1 <= 64 && c2 <= 64 && c3 <= 64;
     if (ns <= 32 && !narrow) return launch_pre<32>(a, b, (hipStream_t)s);

@@ -1,7 +1,5 @@
 // Shared trunk of PoseScoreNet / PoseEnergyNet for one tile of pose rows (included by scorenet.hip and rk45.hip).
 #pragma once
-#include <stdlib.h>
-
 #include "gp_common.h"
 
 namespace gp_trunk {
@@ -13,16 +11,9 @@ constexpr int HID = 256, HEADS = 768, POSE = 9;
 //   16-row tile, R = 3200: 8 waves (two per SIMD) 24.3 us vs 24.3 us with 4 - the tile is bound by the weight stream and its
 //                          phases are barrier-locked, a second wave per SIMD has nothing different to overlap with;
 //   32-row tile, R = 6400: 8 waves 39.2 us vs 40.9 us with 4 - MFMA-bound, the second wave fills epilogue / barrier bubbles.
-// -DGP_TRUNK_NW16= / -DGP_TRUNK_NW32= re-measure.
-#ifndef GP_TRUNK_NW16
-#define GP_TRUNK_NW16 4
-#endif
-#ifndef GP_TRUNK_NW32
-#define GP_TRUNK_NW32 8
-#endif
 template <int P>
 struct TrunkCfg {
-    static constexpr int NW = (P <= 16) ? GP_TRUNK_NW16 : GP_TRUNK_NW32;
+    static constexpr int NW = (P <= 16) ? 4 : 8;
     static constexpr int NV = 16 / NW;   // 16-channel chunks of a 256-wide layer per wave
     static constexpr int NT = 64 * NW;   // threads per workgroup
 };
@@ -34,18 +25,15 @@ struct TrunkCfg {
 // cvt[c] = cvec[first cloud of the tile + c] + tvec.  (Read back with broadcast ds_read_b128; fetching them from global
 // memory in the epilogue costs 1.1-1.7 k cycles per head, and requesting them under the MFMA loop slows the weight
 // stream by more than that - the vector memory path is the loop's bottleneck.)
-// Compact form (GP_TRUNK_DIET_MINP, default: tiles of >= 32 rows): layer 2 runs IN PLACE (H2 aliases H1; every wave keeps its
+// Compact form (tiles of >= 32 rows): layer 2 runs IN PLACE (H2 aliases H1; every wave keeps its
 // outputs in the accumulators until all waves have read H1) and the four lane groups of a wave are combined in registers
 // (v_permlane16/32_swap) before parking: red [NW][P][12].  The 32-row tile takes 64.6 KB instead of 135 KB - a workgroup of another
 // kernel (furthest point sampling, an SA chain kernel of the next batch's encoder) can share the CU with it - and the launch got
 // 3 % FASTER on its own (77.3 -> 75.0 us at 16 000 rows: 37 KB less LDS traffic per head epilogue).  KEEP (the backward pass of
 // gp_score_div reads both hidden activations) keeps H1 and H2 apart.
-#ifndef GP_TRUNK_DIET_MINP
-#define GP_TRUNK_DIET_MINP 32
-#endif
 template <int P, bool KEEP = false>
 struct TrunkLds {
-    static constexpr bool COMPACT = P >= GP_TRUNK_DIET_MINP, INPLACE = COMPACT && !KEEP;
+    static constexpr bool COMPACT = P >= 32, INPLACE = COMPACT && !KEEP;
     static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD, LDC = HEADS + 16;
     static constexpr int OFF_H1 = P * LD0, OFF_H2 = INPLACE ? OFF_H1 : OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH,
                          NRED = (COMPACT ? 1 : 4) * TrunkCfg<P>::NW,
@@ -62,7 +50,6 @@ struct TrunkPreT {
     static constexpr int NWO = (POSE * HID / 4 + 64 * (16 / NV) - 1) / (64 * (16 / NV));   // float4 per thread: w_out
     static constexpr int NCV = (2 * HEADS / 4 + 64 * (16 / NV) - 1) / (64 * (16 / NV));    // float4 per thread: cvt
     f32x4 swo[NWO], scv[NCV], stv[NCV];
-    GpStamps ts;     // tuning builds only
     int cloud0;      // first cloud of the tile
     bool staged;     // tile spans <= 2 clouds (else the epilogue reads cvec/tvec from global memory)
 };
@@ -227,7 +214,6 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         cloud[p] = r / kcand;
     }
     trunk_park_epi<P, KEEP_H1>(lds, pre);  // visible after the barrier that follows layer 1
-    GP_T(2);
     // ---- layer 1 (9 -> 256); layer 2's first weight stages and bias are requested before it runs
     WStages<NV> stB;
     f32x4 b2[NV];
@@ -236,35 +222,21 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
     for (int i = 0; i < NV; ++i) b2[i] = *reinterpret_cast<const f32x4 *>(net.b_pose2 + ncl[i] * 16 + 4 * (lane >> 4));
     trunk_dense<PT, NW>(pre.stA, pre.b0, X0, L::LD0, net.w_pose0, POSE, H1, L::LDH);
     __syncthreads();
-    GP_T(3);
     // ---- layer 2 (256 -> 256); head 0's weights (and, small tile, its epilogue operands) requested before it runs
     WStages<NV> stH[2];
     mfma_preload<NV>(stH[0], net.w_headx, HID / 16, HEADS / 16, nch[0]);
     trunk_dense<PT, NW, L::INPLACE>(stB, b2, H1, L::LDH, net.w_pose2, HID, H2, L::LDH);
-    GP_T(4);
     __syncthreads();
-    GP_T(5);
     // ---- stacked head layer (256 -> 768) with the 256 -> 3 output layers folded into the epilogue
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
         f32x4 acc[4][PT];
-        GP_T(6 + 3 * h);
         // next head's first weight stages are requested before this head runs (hides the cold start)
         if (h < 2) mfma_preload<NV>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
         mfma_run<NV, PT>(stH[h & 1], H2, L::LDH, 0, net.w_headx, HID / 16, HEADS / 16, nch[h], acc);
-        GP_T(7 + 3 * h);
         float part[PT][3];  // [p-chunk][component], this wave's n-chunks of head h
 #pragma unroll
         for (int p = 0; p < PT; ++p) part[p][0] = part[p][1] = part[p][2] = 0.f;
-#ifdef GP_ABL_NOEPI  // ablation build (tuning): the accumulators are consumed, the epilogue arithmetic is not done
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-#pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                asm volatile("" ::"v"(acc[i][p]));
-                part[p][i % 3] = acc[i][p].x;
-            }
-#else
         HeadOps<PT, NV> o;
         head_ops_load<P, PT, NV, KEEP_H1>(o, lds, pre.staged, cvec, tvec, h, nch[h], cloud, pre.cloud0);
 #pragma unroll
@@ -282,7 +254,6 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
                 part[p][2] += v.x * o.w2[i].x + v.y * o.w2[i].y + v.z * o.w2[i].z + v.w * o.w2[i].w;
             }
         }
-#endif
         if constexpr (L::COMPACT) {
             // the 4 channel groups of the wave are summed in registers, one partial per wave is parked
 #pragma unroll
@@ -302,7 +273,6 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
 #pragma unroll
                 for (int c = 0; c < 3; ++c) red[((wave * 4 + (lane >> 4)) * P + p * 16 + (lane & 15)) * 12 + 3 * h + c] = part[p][c];
         }
-        GP_T(8 + 3 * h);
     }
     __syncthreads();
     constexpr int NI = (P * POSE + NT - 1) / NT;
@@ -340,21 +310,45 @@ constexpr size_t trunk_lds_bytes() {
     return (size_t)TrunkLds<P>::TOTAL * sizeof(float);
 }
 
-// Rows per workgroup tile.  With 16 rows every weight fragment feeds one MFMA and the kernel is bound by the CU's
-// L2->VGPR streaming rate (~26 us per round of <= 256 tiles, two tiles co-resident per CU stream twice the bytes); with
-// 32 rows it is MFMA-bound (~42 us per round of <= 256 tiles, one per CU).  Measured on MI355X, K = 50:
-//   R = 3200: 26 / 42 us    6400: 53 / 42    9600: 74 / 82    12800: 98 / 83   (16 / 32 rows)
-// -> pick the smaller of 13*rounds(16) and 21*rounds(32).  GP_SCORE_P overrides (tuning).
-static inline int score_tile_rows(int nrows) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("GP_SCORE_P");
-        forced = e ? atoi(e) : 0;
-    }
-    if (forced == 16 || forced == 32) return forced;
-    const int r16 = ((nrows + 15) / 16 + 255) / 256, r32 = ((nrows + 31) / 32 + 255) / 256;
-    return 21 * r32 < 13 * r16 ? 32 : 16;
+// Rows per workgroup of a score launch: which form of the trunk serves `nrows` rows best.
+//   16 / 32   tile form (this file): one 16- or 32-row tile per workgroup.  With 16 rows every weight fragment feeds one MFMA and the
+//             kernel is bound by the CU's L2 -> VGPR streaming rate; with 32 rows it is MFMA-bound.
+//   128       chain form (trunk_chain.h): 4 waves x 32 rows, activations register-resident, weights through an LDS ring; one
+//             workgroup per CU, one pass over the weights per 128 rows.
+// Measured on MI355X, K = 50, us per launch (profiles/r3_plans.txt):
+//     rows     3200   6400  12800  16000  32000  64000
+//     16       26.1   50.8   96.8   95.0  180.5  346
+//     32       39.7   39.7   75.0   74.8  146.6  290
+//     128     140.2  140.9  142.7  141.7  141.9  283
+// i.e. a ROUND of <= 256 workgroups costs 24.5 / 37.5 / 141.5 us; the plan with the smallest predicted launch time is taken.
+constexpr float TILE16_ROUND_US = 24.5f, TILE32_ROUND_US = 37.5f, CHAIN128_ROUND_US = 141.5f;
+static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
+    // a workgroup never straddles two batches; the chain form stages cvec + tvec of <= 4 clouds per workgroup (trunk_chain.h: NCL)
+    auto fits = [&](int rows) {
+        return (rows_per_group <= 0 || rows_per_group % rows == 0) && (rows < 128 || (rows - 2 + kcand) / kcand + 1 <= 4);
+    };
+    const float inf = 1e30f;
+    const int t16 = (nrows + 15) / 16, t32 = (nrows + 31) / 32, w128 = (nrows + 127) / 128;
+    const float c16 = fits(16) ? TILE16_ROUND_US * ((t16 + 255) / 256) : inf;
+    const float c32 = fits(32) ? TILE32_ROUND_US * ((t32 + 255) / 256) : inf;
+    const float c128 = fits(128) ? CHAIN128_ROUND_US * ((w128 + 255) / 256) : inf;
+    int best = 16;
+    float cb = c16;
+    if (c32 < cb) best = 32, cb = c32;
+    if (c128 < cb) best = 128, cb = c128;
+    return cb < inf ? best : -1;
 }
+// tile form only (entry points that have no chain form: ragged RK45 groups, the backward kernels)
+static inline int score_tile_rows(int nrows) {
+    const int r16 = ((nrows + 15) / 16 + 255) / 256, r32 = ((nrows + 31) / 32 + 255) / 256;
+    return TILE32_ROUND_US * r32 < TILE16_ROUND_US * r16 ? 32 : 16;
+}
+
+// One predictor-corrector update of a row (samplers.py:129-152): Langevin corrector with the batch-mean gradient norm `gn`,
+// renormalisation of the two rotation columns, Euler-Maruyama predictor with the PRE-corrector score and the reference's sign,
+// normalize_rotation.  xv: state in / out; mx: the predictor mean (before its noise; mean_x of the last step).
+__device__ __forceinline__ void pc_update_row(float (&xv)[9], const float (&gr)[9], const float (&zz1)[9], const float (&zz2)[9], float gn, float g,
+                                              float dt, float sqdt, float (&mx)[9]);
 
 // Gram-Schmidt of pytorch3d.rotation_6d_to_matrix + GenPose's column write-back (utils/misc.py:259-265):
 // b1 = a1/max(|a1|,1e-12); b2 = a2 - (b1.a2) b1; b2 /= max(|b2|,1e-12)
@@ -370,6 +364,30 @@ __device__ __forceinline__ void normalize_rot6(T *v) {
     n2 = n2 > eps ? n2 : eps;
     v[0] = b0, v[1] = b1, v[2] = b2;
     v[3] = c0 / n2, v[4] = c1 / n2, v[5] = c2 / n2;
+}
+
+__device__ __forceinline__ void pc_update_row(float (&xv)[9], const float (&gr)[9], const float (&zz1)[9], const float (&zz2)[9], float gn, float g,
+                                              float dt, float sqdt, float (&mx)[9]) {
+    const float q = 0.48f / gn;  // snr * sqrt(pose_dim) = 0.16 * 3
+    const float lstep = 2.0f * (q * q);
+    const float ns = sqrtf(2.0f * lstep);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) xv[j] = (xv[j] + lstep * gr[j]) + ns * zz1[j];
+    const float n1 = sqrtf(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2]);
+    const float n2 = sqrtf(xv[3] * xv[3] + xv[4] * xv[4] + xv[5] * xv[5]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        xv[j] /= n1;
+        xv[3 + j] /= n2;
+    }
+    const float g2 = g * g;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const float drift = 0.f - g2 * gr[j];  // sign as written in the reference (samplers.py:147)
+        mx[j] = xv[j] + drift * dt;
+        xv[j] = mx[j] + (g * sqdt) * zz2[j];
+    }
+    normalize_rot6(xv);
 }
 
 }  // namespace gp_trunk

@@ -8,7 +8,7 @@
 //                + W1x . pose_feat (per row, per evaluation: here, on fp32 MFMA)
 // The three heads are stacked into one 768-wide layer; their 256->3 output layers are applied in the
 // accumulator epilogue (no 768-wide activation ever reaches LDS).
-#include "score_trunk.h"
+#include "trunk_chain.h"
 
 namespace {
 
@@ -114,15 +114,59 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void score_eval_kernel(int nrows, 
     }
 }
 
+// chain form (trunk_chain.h): one wave per 16 rows, the row's pose and outputs stay in its lanes
+template <int PT>
+__global__ __launch_bounds__(gp_chain::NT, 1) void score_eval_chain_kernel(int nrows, int kcand, gp_scorenet net, const float *__restrict__ cvec,
+                                                                                                 const float *__restrict__ tvec, const float *__restrict__ x,
+                                                                                                 const float *__restrict__ sigma_dev, int mode, float *__restrict__ out) {
+    using C = gp_chain::Cfg<PT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pt = lane & 15, g = lane >> 4;
+    const int wg_row0 = blockIdx.x * C::ROWS;
+    gp_chain::State<PT> st;
+    gp_chain::begin<PT>(st, lds, net, cvec, tvec, wg_row0, nrows, kcand);
+    const float sigma = *sigma_dev;
+    float xv[PT][POSE];
+    f32x4 xf[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        int r = wg_row0 + (wave * PT + p) * 16 + pt;
+        r = r < nrows ? r : nrows - 1;  // rows past the end: clamped duplicates (computed, never stored)
+#pragma unroll
+        for (int j = 0; j < POSE; ++j) xv[p][j] = x[(size_t)r * POSE + j];
+        xf[p] = gp_chain::pose_fragment(xv[p], g);
+    }
+    float f[PT][POSE];
+    gp_chain::run<PT>(st, lds, net, xf, f);
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int r = wg_row0 + (wave * PT + p) * 16 + pt;
+        if (r >= nrows || g != 0) continue;
+        if (mode == 0) {
+#pragma unroll
+            for (int j = 0; j < POSE; ++j) out[(size_t)r * POSE + j] = f[p][j] / (sigma + 1e-7f);
+        } else {
+            float er = 0.f, et = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) er += xv[p][j] * (f[p][j] / sigma);
+#pragma unroll
+            for (int j = 6; j < 9; ++j) et += xv[p][j] * (f[p][j] / sigma);
+            out[(size_t)r * 2 + 0] = er;
+            out[(size_t)r * 2 + 1] = et;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- PC sampler
 struct PcArgs {
-    int nrows, kcand, step, nsteps, nblocks;
-    int bpg, rows_per_group;         // blocks / rows of one batch (group): the batch-mean gradient norm is per group
+    int nrows, kcand, step, nsteps;
+    int nparts, ppg, rows_per_group;  // partial sums of |score| per step / per batch (group): the batch-mean gradient norm is per group
+    int wgpg;                         // workgroups per group
     const float *cvec, *tvec_all;    // tvec_all [nsteps][768]
     const float *sched;              // [nsteps][4]: sigma(t_i), g(t_i), step_size, sqrt(step_size)  (f32, host schedule)
     const float *z_lang, *z_pred;    // [nsteps][R][9]
     const float *centre;             // [R/k... per cloud][3]
-    float *x, *mean_x, *score, *partials, *traj;  // x,mean_x,score [R,9]; partials [nsteps][nblocks]; traj [nsteps][R][9] or null
+    float *x, *mean_x, *score, *partials, *traj;  // x,mean_x,score [R,9]; partials [nsteps][nparts]; traj [nsteps][R][9] or null
     const float *gn_ext;             // [nsteps][ngroups] or null: the batch-mean gradient norm supplied from outside (a batch that is
     int ngroups;                     //   sharded over several GPUs: the mean over ALL its rows, all-reduced between the launches)
 };
@@ -138,27 +182,14 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_gn;
     const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
-    // GP_ABL_*: ablation builds (tuning; scratch/r2_ablation.sh, profiles/r2_sampler_ablation.txt) - what each phase of a launch costs
-#ifdef GP_ABL_EMPTY  // the launch itself
-    return;
-#endif
-#ifdef GP_ABL_NOPRO
-    if (i == a.nsteps) return;
-#endif
     TrunkPre<P> pre;
-    GP_WG_BEGIN();
-    GP_T(0);
     float sigma = 1.f;
     if (i < a.nsteps) {
         trunk_begin<P>(net, pre, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand);
         sigma = a.sched[(size_t)i * 4 + 0];  // requested now, used after the trunk
         gp_pin(sigma);
     }
-#ifdef GP_ABL_NOPRO  // no operand loads / batch-mean reduction / PC update
-    if (false) {
-#else
     if (i > 0) {
-#endif
         // (1) row threads request their operands first; (2) meanwhile the last wave reduces the per-block partial sums
         // of step i-1 into the batch-mean gradient norm (fixed order: deterministic); (3) one barrier, then the update.
         const bool live = row0 + tid < a.nrows;
@@ -181,38 +212,18 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         }
         constexpr int LASTW = TrunkCfg<P>::NT - 64;
         if (a.gn_ext) {
-            if (tid == LASTW) s_gn = a.gn_ext[(size_t)(i - 1) * a.ngroups + blockIdx.x / a.bpg];
+            if (tid == LASTW) s_gn = a.gn_ext[(size_t)(i - 1) * a.ngroups + blockIdx.x / a.wgpg];
         } else if (tid >= LASTW) {
             float s = 0.f;
-            const float *pp = a.partials + (size_t)(i - 1) * a.nblocks + (size_t)(blockIdx.x / a.bpg) * a.bpg;
-            for (int q = tid - LASTW; q < a.bpg; q += 64) s += pp[q];
+            const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)(blockIdx.x / a.wgpg) * a.ppg;
+            for (int q = tid - LASTW; q < a.ppg; q += 64) s += pp[q];
             s = wave_sum_f32(s);
             if (tid == LASTW) s_gn = s / (float)a.rows_per_group;
         }
         __syncthreads();
-        GP_T(19);
         if (tid < P) {
-            const float q = 0.48f / s_gn;  // snr * sqrt(pose_dim) = 0.16 * 3
-            const float lstep = 2.0f * (q * q);
-            const float ns = sqrtf(2.0f * lstep);
-#pragma unroll
-            for (int j = 0; j < 9; ++j) xv[j] = (xv[j] + lstep * gr[j]) + ns * zz1[j];
-            float n1 = sqrtf(xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2]);
-            float n2 = sqrtf(xv[3] * xv[3] + xv[4] * xv[4] + xv[5] * xv[5]);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                xv[j] /= n1;
-                xv[3 + j] /= n2;
-            }
-            const float g2 = g * g;
             float mx[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const float drift = 0.f - g2 * gr[j];  // sign as written in the reference (samplers.py:147)
-                mx[j] = xv[j] + drift * dt;
-                xv[j] = mx[j] + (g * sqdt) * zz2[j];
-            }
-            normalize_rot6(xv);
+            pc_update_row(xv, gr, zz1, zz2, s_gn, g, dt, sqdt, mx);
             if (live) {
                 if (a.traj) {
                     float *tr = a.traj + ((size_t)(i - 1) * a.nrows + r) * 9;
@@ -243,12 +254,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         load_x_tile<P>(lds, a.x, row0, a.nrows);
     }
     __syncthreads();
-    GP_T(1);
     trunk_ftheta<P>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre);
-    GP_T(16);
-#ifdef GP_ABL_NOTAIL  // no score write / norm partial
-    if (sigma != 12345.f) return;
-#endif
     float *F = lds + L::OFF_H1;
     for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
         const int r = e / POSE, j = e - r * POSE;
@@ -268,14 +274,146 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
             }
         }
         s = wave_sum_f32(s);
-        if (tid == 0) a.partials[(size_t)i * a.nblocks + blockIdx.x] = s;
+        if (tid == 0) a.partials[(size_t)i * a.nparts + blockIdx.x] = s;
     }
-    GP_T(17);
-    GP_T_FLUSH();
-    GP_WG_END();
+}
+
+// The same launch in the chain form (trunk_chain.h).  A wave owns 16 * PT rows from the sampler update to the score: every lane
+// of a row's four lane groups carries the row's 9-vector (the update is ~150 VALU instructions per wave, computed redundantly by
+// the four groups - cheaper than any exchange), lane group 0 stores.  One partial sum of |score| per WAVE; the batch-mean
+// gradient norm is reduced from them by every wave in the same fixed order (identical in all waves: deterministic).
+template <int PT>
+__global__ __launch_bounds__(gp_chain::NT, 1) void pc_step_chain_kernel(PcArgs a, gp_scorenet net) {
+    using C = gp_chain::Cfg<PT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pt = lane & 15, g = lane >> 4, i = a.step;
+    const int wg_row0 = blockIdx.x * C::ROWS;
+    gp_chain::State<PT> st;
+    const float *tvec = a.tvec_all + (size_t)(i < a.nsteps ? i : 0) * HEADS;
+    int row[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) row[p] = wg_row0 + (wave * PT + p) * 16 + pt;
+    // ---- the rows' operands are requested first, the ring prologue behind them: one memory round trip covers both
+    float xv[PT][9], gr[PT][9], zz1[PT][9], zz2[PT][9], cen[PT][3];
+    float gdiff = 0.f, dt = 0.f, sqdt = 0.f, gn = 1.f, sigma = 1.f;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int r = row[p] < a.nrows ? row[p] : a.nrows - 1;  // rows past the end: clamped duplicates (computed, never stored)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) xv[p][j] = a.x[(size_t)r * 9 + j];
+        if (i > 0) {
+            const float *z1 = a.z_lang + ((size_t)(i - 1) * a.nrows + r) * 9;
+            const float *z2 = a.z_pred + ((size_t)(i - 1) * a.nrows + r) * 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                gr[p][j] = a.score[(size_t)r * 9 + j];
+                zz1[p][j] = z1[j];
+                zz2[p][j] = z2[j];
+            }
+            const float *cp = a.centre + (size_t)(r / a.kcand) * 3;
+            cen[p][0] = cp[0], cen[p][1] = cp[1], cen[p][2] = cp[2];
+        }
+    }
+    if (i > 0) {
+        const float *sc = a.sched + (size_t)(i - 1) * 4;
+        gdiff = sc[1], dt = sc[2], sqdt = sc[3];
+        const int grp = blockIdx.x / a.wgpg;
+        if (a.gn_ext) {
+            gn = a.gn_ext[(size_t)(i - 1) * a.ngroups + grp];
+        } else {
+            float s = 0.f;
+            const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)grp * a.ppg;
+            for (int q = lane; q < a.ppg; q += 64) s += pp[q];
+            gn = wave_sum_f32(s) / (float)a.rows_per_group;
+        }
+    }
+    if (i < a.nsteps) {
+        gp_chain::begin<PT>(st, lds, net, a.cvec, tvec, wg_row0, a.nrows, a.kcand);
+        sigma = a.sched[(size_t)i * 4 + 0];
+    }
+    f32x4 xf[PT];
+    if (i > 0) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            float mx[9];
+            pc_update_row(xv[p], gr[p], zz1[p], zz2[p], gn, gdiff, dt, sqdt, mx);
+            if (row[p] < a.nrows && g == 0) {
+                const int r = row[p];
+                if (a.traj) {
+                    float *tr = a.traj + ((size_t)(i - 1) * a.nrows + r) * 9;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) tr[j] = xv[p][j];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) tr[6 + j] = xv[p][6 + j] + cen[p][j];
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) a.x[(size_t)r * 9 + j] = xv[p][j];
+                if (i == a.nsteps) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) mx[6 + j] += cen[p][j];
+                    normalize_rot6(mx);
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) a.mean_x[(size_t)r * 9 + j] = mx[j];
+                }
+            }
+        }
+        if (i == a.nsteps) return;
+    }
+#pragma unroll
+    for (int p = 0; p < PT; ++p) xf[p] = gp_chain::pose_fragment(xv[p], g);
+    float f[PT][POSE];
+    gp_chain::run<PT>(st, lds, net, xf, f);
+    float nsum = 0.f;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        float q = 0.f, sc9[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            sc9[j] = f[p][j] / (sigma + 1e-7f);
+            q += sc9[j] * sc9[j];
+        }
+        if (row[p] < a.nrows && g == 0) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) a.score[(size_t)row[p] * 9 + j] = sc9[j];
+            nsum += sqrtf(q);
+        }
+    }
+    nsum = wave_sum_f32(nsum);
+    if (lane == 0) a.partials[(size_t)i * a.nparts + (size_t)blockIdx.x * gp_chain::NW + wave] = nsum;
+}
+
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? GP_OK : GP_ELAUNCH;
 }
 
 }  // namespace
+
+template <int PT>
+static int launch_eval_chain(int R, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x, const float *sigma_dev, int mode,
+                             float *out, hipStream_t st) {
+    using C = gp_chain::Cfg<PT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (set_lds(score_eval_chain_kernel<PT>, C::LDS_BYTES)) return GP_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((score_eval_chain_kernel<PT>), dim3((R + C::ROWS - 1) / C::ROWS), dim3(gp_chain::NT), C::LDS_BYTES, st, R, k, *net, cvec, tvec, x,
+                       sigma_dev, mode, out);
+    return gp_launch_status();
+}
+
+template <int PT>
+static int launch_pc_chain(const PcArgs &a, const gp_scorenet *net, int nwg, hipStream_t st) {
+    using C = gp_chain::Cfg<PT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (set_lds(pc_step_chain_kernel<PT>, C::LDS_BYTES)) return GP_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pc_step_chain_kernel<PT>), dim3(nwg), dim3(gp_chain::NT), C::LDS_BYTES, st, a, *net);
+    return gp_launch_status();
+}
 
 extern "C" {
 
@@ -310,28 +448,32 @@ int gp_time_embed_strided(int nt, int ngroups, int64_t t_stride_floats, const gp
     return gp_launch_status();
 }
 
-int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x,
-                  const float *sigma_dev, int mode, float *out, gp_stream_t s) {
+int gp_score_eval_plan(int tile, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x,
+                       const float *sigma_dev, int mode, float *out, gp_stream_t s) {
     if (nclouds < 0 || k <= 0 || !net || !cvec || !tvec || !x || !sigma_dev || !out || (mode != 0 && mode != 1)) return GP_EINVAL;
     const int R = nclouds * k;
     if (R == 0) return GP_OK;
-    const int P = score_tile_rows(R);
+    const int P = tile == 0 ? score_plan_rows(R, 0, k) : tile;
+    hipStream_t st = (hipStream_t)s;
+    if (P == 128) return gp_chain::Cfg<2>::fits(k) ? launch_eval_chain<2>(R, k, net, cvec, tvec, x, sigma_dev, mode, out, st) : GP_EINVAL;
+    if (P != 16 && P != 32) return GP_EINVAL;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(score_eval_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)trunk_lds_bytes<16>()) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(score_eval_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)trunk_lds_bytes<32>()) != hipSuccess)
-            return GP_ELAUNCH;
+        if (set_lds(score_eval_kernel<16>, trunk_lds_bytes<16>()) || set_lds(score_eval_kernel<32>, trunk_lds_bytes<32>())) return GP_ELAUNCH;
         attr_done = true;
     }
     if (P == 16)
-        hipLaunchKernelGGL(score_eval_kernel<16>, dim3((R + 15) / 16), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), (hipStream_t)s, R, k, *net, cvec, tvec,
-                           x, sigma_dev, mode, out);
+        hipLaunchKernelGGL(score_eval_kernel<16>, dim3((R + 15) / 16), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), st, R, k, *net, cvec, tvec, x, sigma_dev,
+                           mode, out);
     else
-        hipLaunchKernelGGL(score_eval_kernel<32>, dim3((R + 31) / 32), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), (hipStream_t)s, R, k, *net, cvec, tvec,
-                           x, sigma_dev, mode, out);
+        hipLaunchKernelGGL(score_eval_kernel<32>, dim3((R + 31) / 32), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), st, R, k, *net, cvec, tvec, x, sigma_dev,
+                           mode, out);
     return gp_launch_status();
+}
+
+int gp_score_eval(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x, const float *sigma_dev, int mode,
+                  float *out, gp_stream_t s) {
+    return gp_score_eval_plan(0, nclouds, k, net, cvec, tvec, x, sigma_dev, mode, out, s);
 }
 
 int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k) {
@@ -343,50 +485,76 @@ int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k) {
     return P;
 }
 
-int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
-                       const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
-                       float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s) {
-    return gp_pc_step_coupled(ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x,
-                              score, partials, traj, nullptr, s);
+// rows per partial sum of |score| for a plan
+static int pc_rows_per_partial(int P) { return P == 16 || P == 32 ? P : P / gp_chain::NW; }  // tile form: per workgroup; chain form: per wave
+static int pc_rows_per_wg(int P) { return P; }
+
+int gp_pc_layout(int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out) {
+    if (ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || !tile_out || !nparts_out) return GP_EINVAL;
+    const int rg = nclouds_per_group * k;
+    int P = tile;
+    if (P == 0) P = score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    if (P != 16 && P != 32 && P != 128) return GP_EINVAL;
+    if (P == 128 && !gp_chain::Cfg<2>::fits(k)) return GP_EINVAL;
+    if (ngroups > 1 && rg % pc_rows_per_wg(P) != 0) return GP_EINVAL;  // a workgroup must not straddle two batches
+    const int rpp = pc_rows_per_partial(P);
+    *tile_out = P;
+    *nparts_out = ngroups * ((rg + pc_rows_per_wg(P) - 1) / pc_rows_per_wg(P)) * (pc_rows_per_wg(P) / rpp);
+    return GP_OK;
 }
 
-int gp_pc_step_coupled(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
-                       const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
-                       float *x, float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
+int gp_pc_step_plan(int tile, int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+                    const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x,
+                    float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
     if (ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || step < 0 || step > nsteps || !net || !cvec || !tvec_all || !sched || !z_langevin ||
         !z_predictor || !centre || !x || !mean_x || !score || !partials)
         return GP_EINVAL;
     const int rg = nclouds_per_group * k, R = ngroups * rg;
     if (R == 0) return GP_OK;
-    const int P = gp_pc_tile_rows(ngroups, nclouds_per_group, k);
-    if (P < 0) return P;
+    int P = 0, nparts = 0;
+    const int rc = gp_pc_layout(tile, ngroups, nclouds_per_group, k, &P, &nparts);
+    if (rc != GP_OK) return rc;
     PcArgs a;
     a.nrows = R, a.kcand = k, a.step = step, a.nsteps = nsteps;
-    a.bpg = (rg + P - 1) / P, a.rows_per_group = rg, a.nblocks = a.bpg * ngroups;
+    a.nparts = nparts, a.ppg = nparts / ngroups, a.rows_per_group = rg;
+    a.wgpg = (rg + pc_rows_per_wg(P) - 1) / pc_rows_per_wg(P);
     a.cvec = cvec, a.tvec_all = tvec_all, a.sched = sched, a.z_lang = z_langevin, a.z_pred = z_predictor, a.centre = centre;
     a.x = x, a.mean_x = mean_x, a.score = score, a.partials = partials, a.traj = traj;
     a.gn_ext = gn_ext, a.ngroups = ngroups;
+    hipStream_t st = (hipStream_t)s;
+    const int nwg = a.wgpg * ngroups;
+    if (P == 128) return launch_pc_chain<2>(a, net, nwg, st);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pc_step_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)trunk_lds_bytes<16>()) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(pc_step_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)trunk_lds_bytes<32>()) != hipSuccess)
-            return GP_ELAUNCH;
+        if (set_lds(pc_step_kernel<16>, trunk_lds_bytes<16>()) || set_lds(pc_step_kernel<32>, trunk_lds_bytes<32>())) return GP_ELAUNCH;
         attr_done = true;
     }
     if (P == 16)
-        hipLaunchKernelGGL(pc_step_kernel<16>, dim3(a.nblocks), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), (hipStream_t)s, a, *net);
+        hipLaunchKernelGGL(pc_step_kernel<16>, dim3(nwg), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), st, a, *net);
     else
-        hipLaunchKernelGGL(pc_step_kernel<32>, dim3(a.nblocks), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), (hipStream_t)s, a, *net);
+        hipLaunchKernelGGL(pc_step_kernel<32>, dim3(nwg), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), st, a, *net);
     return gp_launch_status();
+}
+
+int gp_pc_step_coupled(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+                       const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
+                       float *x, float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
+    return gp_pc_step_plan(0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
+                           partials, traj, gn_ext, s);
+}
+
+int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+                       const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
+                       float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s) {
+    return gp_pc_step_plan(0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
+                           partials, traj, nullptr, s);
 }
 
 int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec, const float *tvec_all,
                const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
                float *score, float *partials, float *traj, gp_stream_t s) {
-    return gp_pc_step_grouped(1, nclouds, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
-                              partials, traj, s);
+    return gp_pc_step_plan(0, 1, nclouds, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score, partials, traj,
+                           nullptr, s);
 }
 
 }  // extern "C"

@@ -25,7 +25,7 @@ def pc_schedule(num_steps, eps=EPS):
 class PCSampler:
     """Predictor-corrector sampler state for a fixed (B, K, num_steps): buffers + optional hipGraph of the whole loop."""
 
-    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1, coupling_group=None):
+    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1, coupling_group=None, tile=0):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: one launch chain serves all of
         them, the batch-mean gradient norm (samplers.py:130-132) stays per batch (gp_pc_step_grouped).
 
@@ -40,16 +40,22 @@ class PCSampler:
         self.dev = torch.device(device)
         R = B * K
         self.R = R
-        self.tile = _lib.lib().gp_pc_tile_rows(groups, B // groups, K)
-        if self.tile < 0:
-            raise ValueError(f"{B // groups} clouds x {K} candidates per batch is not a multiple of the 16-row tile; run the batches separately")
-        self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
+        # launch plan (csrc/score_trunk.h: score_plan_rows): 16 / 32 = tile form, 128 = chain form (register-resident trunk, weights
+        # through an LDS ring) for launches of ~32 000 rows and more; `tile` forces one (tests, measurements)
+        import ctypes
+        t_out, n_out = ctypes.c_int(0), ctypes.c_int(0)
+        if _lib.lib().gp_pc_layout(int(tile), groups, B // groups, K, ctypes.byref(t_out), ctypes.byref(n_out)) != 0:
+            raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
+                             "run the batches separately")
+        self.tile, self.nparts = t_out.value, n_out.value
+        self.kernel_name = f"pc_step_kernel<{self.tile}>" if self.tile in (16, 32) else \
+            "pc_step_chain_kernel<2>"
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)
         self.tvec_all = net.time_embed(ts.to(self.dev))
         f = lambda *s: torch.empty(*s, device=self.dev)
         self.x, self.mean_x, self.score = f(R, 9), f(R, 9), f(R, 9)
-        self.partials = torch.zeros(num_steps, self.nblocks, device=self.dev)
+        self.partials = torch.zeros(num_steps, self.nparts, device=self.dev)
         self.z1, self.z2 = f(num_steps, R, 9), f(num_steps, R, 9)
         self.cvec, self.centre = f(B, 768), f(B, 3)
         self.traj = f(num_steps, R, 9) if record_traj else None
@@ -66,7 +72,7 @@ class PCSampler:
 
     def launch_step(self, i):
         """Launch i of the chain (0 <= i <= n) on the current stream: finishes step i-1 and, for i < n, evaluates the score at t_i."""
-        _lib.call("gp_pc_step_coupled", self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
+        _lib.call("gp_pc_step_plan", self.tile, self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
                   ptr(self.sched), ptr(self.z1), ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
                   ptr(self.traj), ptr(self.gn_ext), stream_ptr())
 

@@ -36,15 +36,16 @@ class ScoreNetHIP:
         _lib.call("gp_time_embed", nt, self.w.ref(), ptr(t_dev), ptr(tvec), stream_ptr())
         return tvec
 
-    def evaluate(self, cvec, k, x, tvec, sigma_dev, mode="score", out=None):
-        """x [B*k,9] f32; cvec [B,768]; tvec [768]; sigma_dev [1] f32 -> score [B*k,9] or energy [B*k,2]"""
+    def evaluate(self, cvec, k, x, tvec, sigma_dev, mode="score", out=None, tile=0):
+        """x [B*k,9] f32; cvec [B,768]; tvec [768]; sigma_dev [1] f32 -> score [B*k,9] or energy [B*k,2].
+        tile: launch plan (0 = automatic; 16 / 32 tile form, 128 chain form - include/genpose_hip.h: gp_score_eval_plan)"""
         _lib.check_device()
         B = cvec.shape[0]
         R = B * k
         m = 0 if mode == "score" else 1
         if out is None:
             out = torch.empty(R, 9 if m == 0 else 2, device=self.device)
-        _lib.call("gp_score_eval", B, k, self.w.ref(), ptr(cvec), ptr(tvec), ptr(x), ptr(sigma_dev), m, ptr(out), stream_ptr())
+        _lib.call("gp_score_eval_plan", int(tile), B, k, self.w.ref(), ptr(cvec), ptr(tvec), ptr(x), ptr(sigma_dev), m, ptr(out), stream_ptr())
         return out
 
     def score_and_divergence(self, cvec, k, x, eps, tvec, sigma_dev):

@@ -182,7 +182,14 @@ int gp_score_div(int nclouds, int k, const gp_scorenet *net, const float *cvec, 
 int gp_energy_score(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x, const float *sigma_dev,
                     float *score, float *energy, gp_stream_t s);
 
-/* Rows per workgroup tile of the score kernels (size of `partials` = nsteps * ceil(R / tile)). */
+/* gp_score_eval with the launch plan chosen by the caller: tile = 0 (automatic, = gp_score_eval), 16 / 32 (tile form: one 16- or
+ * 32-row tile per workgroup, activations through LDS), 128 (chain form: 4 waves x 32 rows per workgroup, activations
+ * register-resident, weights through an LDS ring - csrc/trunk_chain.h; pays from ~32 000 rows; needs k >= 43 so that the rows of a
+ * workgroup span at most 4 clouds, else GP_EINVAL). */
+int gp_score_eval_plan(int tile, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x,
+                       const float *sigma_dev, int mode, float *out, gp_stream_t s);
+
+/* Rows per workgroup tile of the TILE-form score kernels (the RK45 driver and the backward kernels use the tile form only). */
 int gp_score_tile_rows(int nrows);
 
 /* One launch of the predictor-corrector sampler (cond_pc_sampler, samplers.py:102-160), score evaluation fused in.
@@ -202,13 +209,23 @@ int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net,
 /* The same launch over `ngroups` independent batches of `nclouds_per_group` clouds laid out back to back (rows, clouds,
  * noise: group-major).  Everything is row-local except the batch-mean gradient norm, which stays PER GROUP, so every
  * group's result is what gp_pc_step returns for it alone (up to the summation order of the norm partials); serving
- * two batches per launch lets the kernel use 32-row tiles (MFMA-bound) where one batch only fills 16-row tiles
- * (weight-stream-bound).  Rows of one group must be a multiple of the tile: gp_pc_tile_rows() returns the tile
- * (16 or 32) or GP_EINVAL.  partials: [nsteps][ngroups * ceil(rows_per_group / tile)]. */
+ * several batches per launch lets the kernel use 32-row tiles or the chain form (MFMA-bound) where one batch only fills 16-row
+ * tiles (weight-stream-bound).  Rows of one group must be a multiple of the plan's workgroup rows; partials: [nsteps][nparts] with
+ * nparts from gp_pc_layout(0, ...).  gp_pc_tile_rows() = the TILE-form choice (16 or 32, or GP_EINVAL) the RK45 driver uses. */
 int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k);
 int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor,
                        const float *centre, float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s);
+
+/* Launch plan of the PC sampler for (ngroups x nclouds_per_group clouds x k candidates): tile = 0 asks for the automatic choice, else
+ * 16 / 32 / 128 as in gp_score_eval_plan.  *tile_out = the plan taken, *nparts_out = partial sums of |score| per step
+ * (`partials` must hold nsteps * nparts floats: one per workgroup in the tile form, one per wave in the chain form).  GP_EINVAL when a
+ * workgroup of the plan would straddle two groups. */
+int gp_pc_layout(int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out);
+/* gp_pc_step_coupled with the plan chosen by the caller (tile as above; 0 = automatic).  Every launch of one chain must use the same plan. */
+int gp_pc_step_plan(int tile, int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+                    const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x,
+                    float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s);
 
 /* The same launch with the batch-mean gradient norm SUPPLIED: gn_ext [nsteps][ngroups] (device) holds, for step i, the mean of
  * |score_i| over ALL rows of the batch each group belongs to.  For a batch that is sharded over several GPUs (SURVEY §8e caveat): the
