@@ -1,6 +1,7 @@
-"""Training step of the score model: denoising-score-matching loss, optimiser step, EMA - what
-`PoseNet.train_func(data, gf_mode='score')` does in the reference (networks/posenet_agent.py:285-317, 176-197, 530-540;
-networks/gf_algorithms/losses.py:47-89; networks/gf_algorithms/score_utils.py:3-92).
+"""Training steps of the score and the energy model: denoising-score-matching loss, the energy model's pairwise
+ranking loss, optimiser step, learning-rate schedule, weight average, checkpoints - what `PoseNet.train_func(data, pose_samples,
+gf_mode)` does in the reference (networks/posenet_agent.py:176-317, 530-550; networks/gf_algorithms/losses.py:47-89;
+networks/reward.py:63-128; utils/metrics.py:83-186).
 
 What runs where.  The PointNet++ grouping operators - furthest point sampling, gather, ball query, group, and the BACKWARD of gather
 and group - are the hand-written gfx950 kernels of libgenpose_hip.so, reached through `genpose_amd.pointnet2_cuda` (the drop-in for the
@@ -14,6 +15,7 @@ The modules carry the reference's parameter names, so `Trainer.state_dict()` loa
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -212,21 +214,55 @@ class TrainableScoreNet(nn.Module):
         return out / (std + 1e-7)
 
 
+class TrainableEnergyNet(TrainableScoreNet):
+    """PoseEnergyNet (energynet.py:34-222) with the shipped options: energy_mode 'IP', s_theta_mode 'score', norm_energy 'identical'.
+    Same parameters (and parameter names) as the score net; what it RETURNS differs:
+      return_item 'energy'  [R,2]  decoupled inner-product energies <x_rot, s_rot>, <x_trans, s_trans>, s = f_theta / std   (:143-198)
+      return_item 'score'   [R,9]  d/dx <x, f_theta(x) / std> by autograd, kept in the graph (create_graph) so that the
+                                   score-matching loss can be back-propagated through it                                   (:200-222)"""
+
+    def f_over_std(self, pts_feat, pose, t):
+        total = torch.cat([pts_feat, self.t_encoder(t.squeeze(1)), self.pose_encoder(pose)], dim=-1)
+        _, std = self.marginal_prob_fn(total, t)
+        f = torch.cat([self.fusion_tail_rot_x(total), self.fusion_tail_rot_y(total), self.fusion_tail_trans(total)], dim=-1)
+        return f / std
+
+    def forward(self, data, return_item="score"):
+        pts_feat, pose, t = data["pts_feat"], data["sampled_pose"], data["t"]
+        if return_item == "energy":
+            s = self.f_over_std(pts_feat, pose, t)
+            return torch.stack([(pose[:, :-3] * s[:, :-3]).sum(-1), (pose[:, -3:] * s[:, -3:]).sum(-1)], dim=-1)
+        if return_item != "score":
+            raise NotImplementedError(return_item)
+        with torch.enable_grad():
+            x = pose.detach().requires_grad_(True)
+            energy = (x * self.f_over_std(pts_feat, x, t)).sum(-1)
+            (score,) = torch.autograd.grad(energy, x, grad_outputs=torch.ones_like(energy), create_graph=True)
+        return score
+
+
 class TrainableGFObjectPose(nn.Module):
-    def __init__(self, marginal_prob_fn):
+    def __init__(self, marginal_prob_fn, posenet_mode="score"):
         super().__init__()
+        if posenet_mode not in ("score", "energy"):
+            raise NotImplementedError(posenet_mode)
+        self.posenet_mode = posenet_mode
         self.pts_encoder = TrainableEncoder()
-        self.pose_score_net = TrainableScoreNet(marginal_prob_fn)
+        self.pose_score_net = (TrainableScoreNet if posenet_mode == "score" else TrainableEnergyNet)(marginal_prob_fn)
 
     def forward(self, data, mode="score"):
         if mode == "pts_feature":
             return self.pts_encoder(data["pts"])
         if mode == "score":
             return self.pose_score_net(data)
+        if mode == "energy":
+            if self.posenet_mode != "energy":
+                raise NotImplementedError("an energy from the score model does not exist in the reference either (posenet.py:154-160)")
+            return self.pose_score_net(data, return_item="energy")
         raise NotImplementedError(mode)
 
 
-# ---------------------------------------------------------------------------------------------- loss, EMA, trainer
+# ---------------------------------------------------------------------------------------------- losses, weight average, trainer
 def dsm_loss(model, data, marginal_prob_fn, eps=EPS, draws=None):
     """Denoising score matching, losses.py:47-89: t ~ U(eps, 1), x = mu + z std, loss = mean_b sum_d std^2 (s(x,t) + z/std)^2.
     draws (tests): (u [bs] uniform(0,1), z [bs,9] standard normal) instead of the generator."""
@@ -244,92 +280,200 @@ def dsm_loss(model, data, marginal_prob_fn, eps=EPS, draws=None):
     return torch.mean(torch.sum(((std ** 2) * (est - target) ** 2).view(bs, -1), dim=-1))
 
 
-class ExponentialMovingAverage:
-    """score_utils.py:3-92 (decay warm-up (1+n)/(10+n))."""
+SYMMETRIC = ("bottle", "can", "bowl")  # + a mug whose handle is not visible (utils/metrics.py:107-113)
 
-    def __init__(self, parameters, decay, use_num_updates=True):
-        if decay < 0.0 or decay > 1.0:
-            raise ValueError("Decay must be between 0 and 1")
-        self.decay = decay
-        self.num_updates = 0 if use_num_updates else None
-        self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
-        self.collected_params = []
 
-    def update(self, parameters):
-        decay = self.decay
-        if self.num_updates is not None:
-            self.num_updates += 1
-            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+def pose_errors(pred9, gt9, class_ids, handle_visibility, synset_names):
+    """get_metrics (utils/metrics.py:157-186, object-to-camera poses): rotation error in degrees - about the y axis only for the
+    symmetric categories - and translation error in centimetres, per row.  Host arithmetic in float64 like the reference's numpy."""
+    from . import rotation
+    R1 = rotation.get_rot_matrix(pred9[:, :6].float()).double().cpu().numpy()
+    R2 = rotation.get_rot_matrix(gt9[:, :6].float()).double().cpu().numpy()
+    T1, T2 = pred9[:, 6:].double().cpu().numpy(), gt9[:, 6:].double().cpu().numpy()
+    # the reference goes through float32 4x4 matrices and divides the rotations by cbrt(det) (metrics.py:100-103)
+    R1, R2, T1, T2 = (np.asarray(a, dtype=np.float32).astype(np.float64) for a in (R1, R2, T1, T2))
+    R1 = R1 / np.cbrt(np.linalg.det(R1))[:, None, None]
+    R2 = R2 / np.cbrt(np.linalg.det(R2))[:, None, None]
+    ids = np.asarray(class_ids).reshape(-1).astype(np.int64)
+    vis = np.asarray(handle_visibility).reshape(-1)
+    names = np.asarray(synset_names)[ids]
+    sym = np.isin(names, SYMMETRIC) | ((names == "mug") & (vis == 0))
+    y1, y2 = R1[:, :, 1], R2[:, :, 1]
+    cos_sym = (y1 * y2).sum(-1) / (np.linalg.norm(y1, axis=-1) * np.linalg.norm(y2, axis=-1))
+    cos_full = (np.einsum("bij,bij->b", R1, R2) - 1.0) / 2.0  # trace(R1 R2^T)
+    theta = np.degrees(np.arccos(np.clip(np.where(sym, cos_sym, cos_full), -1.0, 1.0)))
+    shift = np.linalg.norm(T1 - T2, axis=-1) * 100.0
+    return theta, shift
+
+
+def ranking_loss(energy_by_error):
+    """networks/reward.py:109-128 on energies sorted by pose error (low error first), [bs, K, 2]: over all pairs i < j,
+    1 + (E_j - E_i) / (|E_i - E_j| + 1e-5) - zero when the candidate with the smaller error has the larger energy.  All K(K-1)/2 pairs
+    at once instead of the reference's Python double loop (the mean over pairs of per-pair means over [bs, 2] is the same sum)."""
+    K = energy_by_error.shape[1]
+    i, j = torch.triu_indices(K, K, offset=1, device=energy_by_error.device)
+    ei, ej = energy_by_error[:, i, :], energy_by_error[:, j, :]
+    return (1 + (ej - ei) / (torch.abs(ei - ej) + 1e-5)).mean(dim=(0, 2)).sum() / i.numel()
+
+
+class WeightAverage:
+    """Polyak average of the trainable parameters with the warm-up of the reference (decay = min(rate, (1 + n) / (10 + n)),
+    score_utils.py:35-49), kept as one list of tensors updated by a single fused lerp.  `applied()` runs a block with the averaged
+    weights swapped INTO the network (evaluation, checkpoints) and swaps the raw weights back afterwards - a pointer exchange, no
+    copies."""
+
+    def __init__(self, params, rate):
+        if not 0.0 <= rate <= 1.0:
+            raise ValueError(f"average rate {rate} outside [0, 1]")
+        self.rate, self.steps = rate, 0
+        self.params = [p for p in params if p.requires_grad]
+        self.average = [p.detach().clone() for p in self.params]
+
+    def step(self):
+        self.steps += 1
+        keep = min(self.rate, (1 + self.steps) / (10 + self.steps))
         with torch.no_grad():
-            for s, p in zip(self.shadow_params, [p for p in parameters if p.requires_grad]):
-                s.sub_((1.0 - decay) * (s - p))
+            torch._foreach_lerp_(self.average, [p.detach() for p in self.params], 1.0 - keep)
 
-    def copy_to(self, parameters):
-        for s, p in zip(self.shadow_params, [p for p in parameters if p.requires_grad]):
-            p.data.copy_(s.data)
+    def _swap(self):
+        for p, a in zip(self.params, self.average):
+            p.data, a.data = a.data, p.data
 
-    def store(self, parameters):
-        self.collected_params = [p.clone() for p in parameters]
+    def applied(self):
+        import contextlib
 
-    def restore(self, parameters):
-        for c, p in zip(self.collected_params, parameters):
-            p.data.copy_(c.data)
-
-    def state_dict(self):
-        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
+        @contextlib.contextmanager
+        def ctx():
+            self._swap()
+            try:
+                yield
+            finally:
+                self._swap()
+        return ctx()
 
 
 class Trainer:
-    """The training half of the reference agent for the score model: Adam (or SGD), exponential lr decay, gradient clipping, EMA."""
+    """The training half of the reference agent (networks/posenet_agent.py:46-317, 530-550): Adam (or SGD), linear warm-up then
+    exponential lr decay, gradient clipping, weight average; score model, energy model without (`energy_wo_ranking`) or with the
+    ranking loss (`energy`)."""
 
-    def __init__(self, device="cuda", lr=1e-3, optimizer="Adam", lr_decay=0.98, grad_clip=1.0, ema_rate=0.999, repeat_num=20, sde_mode="ve"):
+    def __init__(self, device="cuda", lr=1e-3, optimizer="Adam", lr_decay=0.98, grad_clip=1.0, ema_rate=0.999, repeat_num=20, sde_mode="ve",
+                 posenet_mode="score", warmup=100, synset_names=("bottle", "bowl", "camera", "can", "laptop", "mug")):
         self.device = torch.device(device)
         self.prior_fn, self.marginal_prob_fn, self.sde_fn, self.sampling_eps, self.T = init_sde(sde_mode)
-        self.net = TrainableGFObjectPose(self.marginal_prob_fn).to(self.device)
+        self.net = TrainableGFObjectPose(self.marginal_prob_fn, posenet_mode).to(self.device)
         if optimizer == "Adam":
             self.optimizer = torch.optim.Adam(self.net.parameters(), betas=(0.9, 0.999), eps=1e-8, lr=lr)
         elif optimizer == "SGD":
             self.optimizer = torch.optim.SGD(self.net.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
         else:
             raise NotImplementedError(optimizer)
+        self.base_lr, self.warmup = lr, warmup
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, lr_decay)
-        self.ema = ExponentialMovingAverage(self.net.parameters(), decay=ema_rate)
-        self.grad_clip, self.repeat_num, self.ema_rate, self.step = grad_clip, repeat_num, ema_rate, 0
+        self.ema = WeightAverage(self.net.parameters(), ema_rate)
+        self.grad_clip, self.repeat_num, self.ema_rate = grad_clip, repeat_num, ema_rate
+        self.synset_names = list(synset_names)
+        self.clock = {"epoch": 1, "minibatch": 0, "step": 0}  # TrainClock (utils/genpose_utils.py:70-96)
 
+    # ------------------------------------------------------------------ state
     def load_state_dict(self, sd, reset_ema=True):
         self.net.load_state_dict({k: v.to(self.device) for k, v in sd.items()})
         if reset_ema:
-            self.ema = ExponentialMovingAverage(self.net.parameters(), decay=self.ema_rate)
+            self.ema = WeightAverage(self.net.parameters(), self.ema_rate)
 
     def state_dict(self, ema=True):
-        """Reference-layout state dict; with ema=True the EMA weights, as save_ckpt stores them (posenet_agent.py:125-140)."""
-        if ema:
-            self.ema.store(self.net.parameters())
-            self.ema.copy_to(self.net.parameters())
-        sd = {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()}
-        if ema:
-            self.ema.restore(self.net.parameters())
-        return sd
+        """Reference-layout state dict; with ema=True the averaged weights, as save_ckpt stores them (posenet_agent.py:125-140)."""
+        if not ema:
+            return {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()}
+        with self.ema.applied():
+            return {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()}
 
+    def save_ckpt(self, path):
+        """The reference's checkpoint dictionary (posenet_agent.py:117-141): averaged weights + optimiser + scheduler + clock."""
+        torch.save({"clock": dict(self.clock), "model_state_dict": self.state_dict(ema=True), "optimizer_state_dict": self.optimizer.state_dict(),
+                    "scheduler_state_dict": self.scheduler.state_dict()}, path)
+
+    def load_ckpt(self, path, load_model_only=False):
+        """posenet_agent.py:143-173 (`module.`-prefixed keys of a DataParallel checkpoint are accepted)."""
+        import os
+        if not os.path.exists(path):
+            raise ValueError("Checkpoint {} not exists.".format(path))
+        ck = torch.load(path, map_location="cpu")
+        self.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in ck["model_state_dict"].items()})
+        if not load_model_only:
+            self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+            self.scheduler.load_state_dict(ck["scheduler_state_dict"])
+            self.clock = dict(ck["clock"])
+
+    def tick(self):
+        self.clock["minibatch"] += 1
+        self.clock["step"] += 1
+
+    def update_learning_rate(self):
+        """posenet_agent.py:543-550: linear warm-up over `warmup` steps, then exponential decay for as long as lr >= 1e-4."""
+        group = self.optimizer.param_groups[-1]
+        if self.clock["step"] <= self.warmup:
+            group["lr"] = self.base_lr / self.warmup * self.clock["step"]
+        elif not group["lr"] < 1e-4:
+            self.scheduler.step()
+
+    # ------------------------------------------------------------------ losses
     def collect_score_loss(self, data, draws=None):
         loss = 0
         for r in range(self.repeat_num):
             loss = loss + dsm_loss(self.net, data, self.marginal_prob_fn, draws=None if draws is None else (draws[0][r], draws[1][r]))
         return {"gf": loss / self.repeat_num}
 
-    def train_func(self, data, gf_mode="score", draws=None):
-        """One step (train_score_func): data['pts'] [B,1024,3], data['zero_mean_pts'], data['zero_mean_gt_pose'] [B,9] on the device."""
-        if gf_mode not in ("score", "energy_wo_ranking"):
-            raise NotImplementedError("training the energy model's ranking loss is not implemented")
-        self.net.train()
-        data["pts_feat"] = self.net(data, mode="pts_feature")
-        losses = self.collect_score_loss(data, draws)
+    def get_energy(self, data, pose_samples, T=None, t_draws=None):
+        """PoseNet.get_energy(mode='train', extract_pts_feature=False) (posenet_agent.py:471-527): energies [bs, K, 2] of the
+        candidates, differentiable w.r.t. the network; T=None draws one T in {1e-5 .. 9e-5} per cloud (t_draws [bs,1] ints 1..9: tests)."""
+        bs, K = pose_samples.shape[:2]
+        feat = data["pts_feat"].unsqueeze(1).expand(bs, K, -1).reshape(bs * K, -1)
+        pose = pose_samples.clone().reshape(bs * K, -1).type_as(feat)
+        if T is not None:
+            t = torch.ones(bs * K, 1).type_as(feat) * T
+        else:
+            ti = torch.randint(1, 10, (bs, 1)) if t_draws is None else t_draws
+            t = (ti.type_as(feat) / 1e5).repeat(1, K).view(bs * K, 1)
+        pose[:, -3:] -= data["pts_center"].unsqueeze(1).expand(bs, K, -1).reshape(bs * K, -1)
+        return self.net({"pts_feat": feat, "sampled_pose": pose, "t": t}, mode="energy").reshape(bs, K, -1)
+
+    def collect_ranking_loss(self, data, pred_pose, t_draws=None):
+        """posenet_agent.py:227-259: energies of the candidates ordered by their pose error (per channel) -> pairwise ranking loss."""
+        energy = self.get_energy(data, pred_pose, t_draws=t_draws)
+        bs, K = pred_pose.shape[:2]
+        rep = lambda v: v.reshape(bs, -1).unsqueeze(1).expand(bs, K, -1).reshape(bs * K, -1)
+        rot_err, trans_err = pose_errors(pred_pose.reshape(bs * K, -1), rep(data["gt_pose"]), rep(data["id"]).cpu().numpy(),
+                                         rep(data["handle_visibility"]).cpu().numpy(), self.synset_names)
+        metrics = torch.from_numpy(np.stack([rot_err, trans_err], axis=-1)).to(energy.device).reshape(bs, K, 2)
+        order = torch.argsort(metrics, dim=1, descending=False)  # reward.py:63-83 (sort_results)
+        return {"ranking": ranking_loss(energy.gather(1, order))}
+
+    def _update_network(self, losses):
         loss = sum(losses.values())
         self.optimizer.zero_grad()
         loss.backward()
         if self.grad_clip >= 0:
             torch.nn.utils.clip_grad_norm_(self.net.parameters(), max_norm=self.grad_clip)
         self.optimizer.step()
-        self.ema.update(self.net.parameters())
-        self.step += 1
+
+    def train_func(self, data, pose_samples=None, gf_mode="score", draws=None, t_draws=None):
+        """One step (posenet_agent.py:310-317).  data on the device: 'pts' [B,1024,3], 'zero_mean_pts', 'zero_mean_gt_pose' [B,9]; for
+        gf_mode 'energy' also 'pts_center', 'gt_pose', 'id', 'handle_visibility' and pose_samples [B,K,9] (candidates of the score
+        model).  'score' / 'energy_wo_ranking' = train_score_func on whatever network the trainer was built with (posenet_mode
+        'score' -> PoseScoreNet; 'energy' -> PoseEnergyNet, whose score is the autograd gradient of its energy)."""
+        if gf_mode not in ("score", "energy_wo_ranking", "energy"):
+            raise NotImplementedError(gf_mode)
+        want = "score" if gf_mode == "score" else "energy"
+        if self.net.posenet_mode != want:
+            raise ValueError(f"gf_mode '{gf_mode}' trains a posenet_mode='{want}' network; this trainer holds a '{self.net.posenet_mode}' one")
+        self.net.train()
+        data["pts_feat"] = self.net(data, mode="pts_feature")
+        losses = self.collect_score_loss(data, draws)
+        if gf_mode == "energy":
+            if pose_samples is None:
+                raise ValueError("gf_mode 'energy' needs pose_samples [B,K,9]")
+            losses.update(self.collect_ranking_loss(data, pose_samples, t_draws))
+        self._update_network(losses)
+        self.ema.step()
         return losses

@@ -19,6 +19,7 @@ What each file pins:
   g9_track.npz    3-frame tracking loop semantics (evaluation_tracking.py:262-337) incl. add_noise_to_RT draws.
   g10..g13        mAP evaluation, depth -> cloud pre-processing, likelihood, score of the energy model (--g10 .. --g13).
   g14_train_step.npz  one training step of the score model (--g14): loss, clipped gradients, Adam update, EMA, BN statistics.
+  g15_energy_train_step.npz  one training step of the energy model incl. the ranking loss (--g15).
 """
 import hashlib
 import os
@@ -455,7 +456,101 @@ def main_g14():
     print("g14_train_step.npz", os.path.getsize(os.path.join(OUT, "g14_train_step.npz")), "loss", g14["loss"])
 
 
+def main_g15():
+    """G15 one training step of the ENERGY model with the ranking loss: the imported reference's own train_energy_func pieces
+    (posenet_agent.py:262-283: net.train(), pts_feature, collect_score_loss on PoseEnergyNet's autograd score, collect_ranking_loss
+    -> get_energy(mode='train') / get_metrics / sort_results / ranking_loss, update_network, ema.update) on 4 clouds x 6 candidate
+    poses, repeat_num = 2, with the torch.rand / torch.randn_like / torch.randint draws logged."""
+    ns = ref_import.load()
+    from networks.gf_algorithms.score_utils import ExponentialMovingAverage
+    ag, sd = make_agent(ns, "energy")
+    ag.cfg.repeat_num, ag.cfg.grad_clip = 2, 1.0
+    ag.ema = ExponentialMovingAverage(ag.net.parameters(), decay=ag.cfg.ema_rate)
+    B, K = 4, 6
+    pts = torch.from_numpy(synth.make_batch(B, start=1500))
+    centre = pts.mean(dim=1)
+    gen = torch.Generator().manual_seed(15)
+
+    def rand_pose(n, trans_scale):
+        a = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        b = torch.randn(n, 3, generator=gen)
+        b = torch.nn.functional.normalize(b - (a * b).sum(-1, keepdim=True) * a, dim=-1)
+        return torch.cat([a, b, trans_scale * torch.randn(n, 3, generator=gen)], dim=-1)
+
+    gt0 = rand_pose(B, 0.05)                        # zero-mean translation
+    gt = gt0.clone()
+    gt[:, 6:] += centre                              # camera-frame ground truth
+    noise = 0.25 * torch.randn(B, K, 9, generator=gen)
+    noise[:, :, 6:] *= 0.1
+    cand = gt.unsqueeze(1) + noise                   # candidates of a (pretend) score model: perturbed ground truth
+    r6 = ns.misc.normalize_rotation(cand.reshape(B * K, 9)[:, :6].clone(), "rot_matrix") if hasattr(ns.misc, "normalize_rotation") else None
+    cand = cand.reshape(B * K, 9)
+    if r6 is not None:
+        cand[:, :6] = r6
+    cand = cand.reshape(B, K, 9)
+    ids = torch.tensor([0, 2, 5, 5])                 # bottle (symmetric), camera, mug without / with a visible handle
+    vis = torch.tensor([1, 1, 0, 1])
+    data = {"pts": pts, "zero_mean_pts": pts - centre.unsqueeze(1), "pts_center": centre, "zero_mean_gt_pose": gt0, "gt_pose": gt,
+            "id": ids, "handle_visibility": vis}
+    draws_u, draws_z, draws_t = [], [], []
+    _rand, _randn_like, _randint = torch.rand, torch.randn_like, torch.randint
+
+    def rand(*a_, **k):
+        r = _rand(*a_, **k)
+        draws_u.append(r.detach().clone())
+        return r
+
+    def randn_like(x, **k):
+        r = _randn_like(x, **k)
+        draws_z.append(r.detach().clone())
+        return r
+
+    def randint(*a_, **k):
+        r = _randint(*a_, **k)
+        draws_t.append(r.detach().clone())
+        return r
+
+    torch.manual_seed(1515)
+    torch.set_grad_enabled(True)
+    torch.rand, torch.randn_like, torch.randint = rand, randn_like, randint
+    try:
+        ag.net.train()
+        ag.is_testing = False
+        data["pts_feat"] = ag.net(data, mode="pts_feature")
+        ag.pts_feature = True
+        losses = {**ag.collect_score_loss(data), **ag.collect_ranking_loss(data, cand)}
+        ag.update_network(losses)
+        ag.ema.update(ag.net.parameters())
+    finally:
+        torch.rand, torch.randn_like, torch.randint = _rand, _randn_like, _randint
+        torch.set_grad_enabled(False)
+    assert len(draws_u) == 2 and len(draws_z) == 2 and len(draws_t) == 1
+    from utils.metrics import get_metrics
+    rot_err, trans_err = get_metrics(cand.reshape(B * K, 9), gt.unsqueeze(1).repeat(1, K, 1).reshape(B * K, 9),
+                                     class_ids=ids.unsqueeze(1).repeat(1, K).reshape(-1, 1), synset_names=ag.cfg.synset_names,
+                                     gt_handle_visibility=vis.unsqueeze(1).repeat(1, K).reshape(-1, 1), pose_mode="rot_matrix", o2c_pose=ag.cfg.o2c_pose)
+    names = [n for n, p_ in ag.net.named_parameters() if p_.requires_grad]
+    params = dict(ag.net.named_parameters())
+    shadow = dict(zip(names, ag.ema.shadow_params))
+    g15 = {"pts": pts.numpy(), "gt_pose": gt.numpy(), "zero_mean_gt_pose": gt0.numpy(), "pose_samples": cand.numpy(), "id": ids.numpy(),
+           "handle_visibility": vis.numpy(), "u": torch.stack(draws_u).numpy(), "z": torch.stack(draws_z).numpy(), "t_draws": draws_t[0].numpy(),
+           "loss_gf": np.float64(losses["gf"].item()), "loss_ranking": np.float64(losses["ranking"].item()),
+           "rot_err": np.asarray(rot_err, dtype=np.float64), "trans_err": np.asarray(trans_err, dtype=np.float64),
+           "param_names": np.array(names), "grad_norms": np.array([float(params[n].grad.norm()) for n in names]),
+           "lr": np.float64(ag.cfg.lr), "ema_rate": np.float64(ag.cfg.ema_rate)}
+    for tag, n in (("enc0", "pts_encoder.SA_modules.0.mlps.0.layer0.conv.weight"), ("pose0", "pose_score_net.pose_encoder.0.weight"),
+                   ("tail", "pose_score_net.fusion_tail_trans.2.weight"), ("head", "pose_score_net.fusion_tail_rot_x.0.weight")):
+        cut = slice(0, 8) if tag == "head" else slice(None)  # [256,1408]: the first rows do
+        g15[f"{tag}_grad"] = params[n].grad.numpy()[cut].copy()
+        g15[f"{tag}_new"] = params[n].detach().numpy()[cut].copy()
+        g15[f"{tag}_ema"] = shadow[n].numpy()[cut].copy()
+    np.savez_compressed(os.path.join(OUT, "g15_energy_train_step.npz"), **g15)
+    print("g15_energy_train_step.npz", os.path.getsize(os.path.join(OUT, "g15_energy_train_step.npz")), "gf", g15["loss_gf"], "ranking", g15["loss_ranking"])
+
+
 if __name__ == "__main__":
+    if "--g15" in sys.argv:
+        sys.exit(main_g15())
     if "--g14" in sys.argv:
         sys.exit(main_g14())
     if "--g13" in sys.argv:

@@ -34,7 +34,7 @@ def _compare(g, tr, losses, tol):
     assert names == list(g["param_names"])  # same parameters in the same order as the reference's net.parameters()
     norms = np.array([float(params[n].grad.norm()) for n in names])
     np.testing.assert_allclose(norms, g["grad_norms"], rtol=20 * tol, atol=tol * g["grad_norms"].max())
-    shadow = dict(zip(names, tr.ema.shadow_params))
+    shadow = dict(zip(names, tr.ema.average))
     for tag, n in (("enc0", "pts_encoder.SA_modules.0.mlps.0.layer0.conv.weight"), ("enc3bn", "pts_encoder.SA_modules.3.mlps.1.layer2.bn.bn.weight"),
                    ("pose0", "pose_score_net.pose_encoder.0.weight"), ("tail", "pose_score_net.fusion_tail_trans.2.weight")):
         gr = params[n].grad.cpu().numpy()
@@ -81,3 +81,132 @@ def test_training_step_on_the_device():
         want = tr.net({"pts": pts}, mode="pts_feature")
     got = agent.net({"pts": pts}, mode="pts_feature")
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------- energy model (fixture G15)
+G15_TAGS = (("enc0", "pts_encoder.SA_modules.0.mlps.0.layer0.conv.weight", slice(None)), ("pose0", "pose_score_net.pose_encoder.0.weight", slice(None)),
+            ("tail", "pose_score_net.fusion_tail_trans.2.weight", slice(None)), ("head", "pose_score_net.fusion_tail_rot_x.0.weight", slice(0, 8)))
+
+
+def _run_energy_step(device, monkeypatch=None):
+    from conftest import load_golden
+    from genpose_amd import training
+    g = load_golden("g15_energy_train_step.npz")
+    if monkeypatch is not None:
+        from oracle import pn2_oracle
+        monkeypatch.setattr(training, "pn2", pn2_oracle.as_pointnet2_cuda_module())
+    tr = training.Trainer(device=device, lr=float(g["lr"]), ema_rate=float(g["ema_rate"]), repeat_num=2, grad_clip=1.0, posenet_mode="energy")
+    tr.load_state_dict(go.make_state_dict(0, "energy"))
+    pts = torch.from_numpy(g["pts"]).to(device)
+    centre = pts.mean(dim=1)
+    data = {"pts": pts, "zero_mean_pts": pts - centre.unsqueeze(1), "pts_center": centre, "zero_mean_gt_pose": torch.from_numpy(g["zero_mean_gt_pose"]).to(device),
+            "gt_pose": torch.from_numpy(g["gt_pose"]).to(device), "id": torch.from_numpy(g["id"]).to(device),
+            "handle_visibility": torch.from_numpy(g["handle_visibility"]).to(device)}
+    cand = torch.from_numpy(g["pose_samples"]).to(device)
+    losses = tr.train_func(data, pose_samples=cand, gf_mode="energy", draws=(torch.from_numpy(g["u"]), torch.from_numpy(g["z"])),
+                           t_draws=torch.from_numpy(g["t_draws"]))
+    return g, tr, losses
+
+
+def _compare_energy(g, tr, losses, tol):
+    assert abs(float(losses["gf"].detach()) - float(g["loss_gf"])) <= tol * abs(float(g["loss_gf"]))
+    assert abs(float(losses["ranking"].detach()) - float(g["loss_ranking"])) <= 10 * tol * abs(float(g["loss_ranking"]))
+    params = dict(tr.net.named_parameters())
+    names = [n for n, p in tr.net.named_parameters() if p.requires_grad]
+    assert names == list(g["param_names"])
+    norms = np.array([float(params[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=20 * tol, atol=tol * g["grad_norms"].max())
+    shadow = dict(zip(names, tr.ema.average))
+    lr = float(g["lr"])
+    for tag, n, cut in G15_TAGS:
+        gr = params[n].grad.cpu().numpy()[cut]
+        np.testing.assert_allclose(gr, g[f"{tag}_grad"], rtol=0, atol=50 * tol * np.abs(g[f"{tag}_grad"]).max(), err_msg=f"{tag} grad")
+        firm = np.abs(g[f"{tag}_grad"]) > 50 * tol * np.abs(g[f"{tag}_grad"]).max()  # Adam's first step = lr * sign(grad): see _compare
+        new, want = params[n].detach().cpu().numpy()[cut], g[f"{tag}_new"]
+        np.testing.assert_allclose(new[firm], want[firm], rtol=0, atol=2e-4, err_msg=f"{tag} after Adam")
+        np.testing.assert_allclose(new[~firm], want[~firm], rtol=0, atol=2.1 * lr, err_msg=f"{tag} after Adam (undetermined sign)")
+        assert np.all(np.abs(shadow[n].cpu().numpy()[cut] - g[f"{tag}_ema"]) <= np.where(firm, 1e-4, 2.1 * lr)), f"{tag} weight average"
+
+
+def test_pose_errors_and_ranking_loss_match_the_reference():
+    """get_metrics (symmetric categories about y, mug by handle visibility) and the pairwise ranking loss, against the values the
+    imported reference produced for fixture G15."""
+    from conftest import load_golden
+    from genpose_amd import training
+    g = load_golden("g15_energy_train_step.npz")
+    cand = torch.from_numpy(g["pose_samples"])
+    B, K = cand.shape[:2]
+    rep = lambda v: torch.from_numpy(v).reshape(B, -1).unsqueeze(1).expand(B, K, -1).reshape(B * K, -1)
+    rot, trans = training.pose_errors(cand.reshape(B * K, 9), rep(g["gt_pose"]), rep(g["id"]).numpy(), rep(g["handle_visibility"]).numpy(),
+                                      ["bottle", "bowl", "camera", "can", "laptop", "mug"])
+    np.testing.assert_allclose(rot, g["rot_err"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(trans, g["trans_err"], rtol=1e-5, atol=1e-6)
+    e = torch.randn(3, 7, 2, generator=torch.Generator().manual_seed(0))
+    loop, count = 0.0, 0
+    for i in range(6):
+        for j in range(i + 1, 7):
+            loop += torch.mean(1 + (-e[:, i, :] + e[:, j, :]) / (torch.abs(e[:, i, :] - e[:, j, :]) + 1e-5))
+            count += 1
+    assert abs(float(training.ranking_loss(e)) - float(loop / count)) < 1e-6
+
+
+def test_energy_training_step_on_the_cpu_with_the_c_operators(monkeypatch):
+    torch.set_num_threads(4)
+    g, tr, losses = _run_energy_step("cpu", monkeypatch)
+    _compare_energy(g, tr, losses, tol=1e-5)
+    assert set(tr.state_dict(ema=True)) == set(go.make_state_dict(0, "energy"))
+
+
+def test_trainer_modes_schedule_and_checkpoints(tmp_path, monkeypatch):
+    """gf_mode / network mismatches are refused; the learning rate warms up linearly and then decays while >= 1e-4
+    (posenet_agent.py:543-550); save_ckpt / load_ckpt round-trip the reference's checkpoint dictionary and resume the optimiser."""
+    import os
+    from genpose_amd import training
+    from oracle import pn2_oracle
+    monkeypatch.setattr(training, "pn2", pn2_oracle.as_pointnet2_cuda_module())
+    tr = training.Trainer(device="cpu", lr=1e-3, warmup=4, lr_decay=0.5, posenet_mode="score")
+    with pytest.raises(ValueError):
+        tr.train_func({}, gf_mode="energy")
+    with pytest.raises(ValueError):
+        tr.train_func({}, gf_mode="energy_wo_ranking")  # that mode trains a PoseEnergyNet (the reference builds one for it)
+    with pytest.raises(NotImplementedError):
+        tr.train_func({}, gf_mode="bogus")
+    lrs = []
+    for _ in range(9):
+        tr.tick()
+        tr.update_learning_rate()
+        lrs.append(tr.optimizer.param_groups[-1]["lr"])
+    np.testing.assert_allclose(lrs[:4], [2.5e-4, 5e-4, 7.5e-4, 1e-3])
+    np.testing.assert_allclose(lrs[4:8], [5e-4, 2.5e-4, 1.25e-4, 6.25e-5])
+    assert lrs[8] == lrs[7]  # below 1e-4 the decay stops
+    path = os.path.join(str(tmp_path), "ckpt_epoch1.pth")
+    tr.save_ckpt(path)
+    ck = torch.load(path)
+    assert set(ck) == {"clock", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"} and ck["clock"]["step"] == 9
+    tr2 = training.Trainer(device="cpu", lr=1e-3, warmup=4, lr_decay=0.5, posenet_mode="score")
+    tr2.load_ckpt(path)
+    assert tr2.clock == tr.clock and tr2.optimizer.param_groups[-1]["lr"] == lrs[-1]
+    for a, b in zip(tr.state_dict(ema=True).values(), tr2.state_dict(ema=False).values()):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        tr2.load_ckpt(os.path.join(str(tmp_path), "missing.pth"))
+    # the weight average: swapped in for a block, swapped back after it
+    w = next(tr.net.parameters())
+    before = w.detach().clone()
+    with torch.no_grad():
+        w.add_(1.0)
+    tr.ema.step()
+    with tr.ema.applied():
+        inside = w.detach().clone()
+    assert torch.allclose(w, before + 1.0) and not torch.allclose(inside, w) and torch.all((inside > before) & (inside < before + 1.0))
+
+
+@pytest.mark.gpu
+def test_energy_training_step_on_the_device():
+    g, tr, losses = _run_energy_step("cuda")
+    _compare_energy(g, tr, losses, tol=2e-4)
+    # an 'energy_wo_ranking' step (score matching through the energy net's autograd score) runs on the device too
+    pts = torch.from_numpy(g["pts"]).cuda()
+    data = {"pts": pts, "zero_mean_pts": pts - pts.mean(dim=1, keepdim=True), "zero_mean_gt_pose": torch.from_numpy(g["zero_mean_gt_pose"]).cuda()}
+    l2 = tr.train_func(data, gf_mode="energy_wo_ranking")
+    assert torch.isfinite(l2["gf"])
