@@ -9,7 +9,7 @@
 //   rk45_finish           : denoise step (samplers.py:209-218), normalize_rotation, + centre
 // The error norm is the reference's batch-global RMS over all R*9 components: per-tile partial sums, reduced in
 // a fixed order by the single-workgroup decide kernel (deterministic).
-#include "score_trunk.h"
+#include "score_bwd.h"
 
 namespace {
 
@@ -77,6 +77,19 @@ struct OdeArgs {
     double *partials;          // [3][nblocks]
     double *traj;              // [traj_cap][R*9] accepted states (raw, un-normalised) or null
     float *x32;                // [R*9] scratch
+    const float *probe;        // [R][9] Hutchinson probe of the likelihood ODE (model 2) or null
+    int ncomp;                 // state components per row: 9 (pose), 10 for the likelihood ODE (pose + log-density change)
+};
+
+// MODEL of the right-hand side (the same Dormand-Prince driver integrates all three):
+//   0  probability-flow ODE of the score network           dx/dt = -g^2/2 . f / (sigma + 1e-7)                 (samplers.py:163-227)
+//   1  the same ODE driven by the ENERGY network's score    ... . d/dx <x, f(x)/sigma>                          (posenet.py:94-130, energynet.py:200-222)
+//   2  likelihood ODE of the score network                  d[x, logp]/dt = -g^2/2 . [score, probe^T J_score probe]   (samplers.py:22-99)
+// Models 1 and 2 need the backward pass of the trunk (score_bwd.h) and run on 16-row tiles.
+template <int MODEL>
+struct OdeModel {
+    static constexpr int NC = MODEL == 2 ? 10 : POSE;
+    static constexpr bool BWD = MODEL != 0;
 };
 
 // which group / rows does this workgroup serve
@@ -105,9 +118,11 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 
 // Fused stage kernel.  STAGE 1..6: Runge-Kutta stage;  STAGE 0: f0 = fun(t0, y0) (+ d0,d1 partials);
 // STAGE 7: f1 = fun(t0 + h0*dir, y0 + h0*dir*f0) (+ d2 partial).
-template <int P, int STAGE>
+template <int P, int STAGE, int MODEL>
 __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, gp_scorenet net) {
-    using L = TrunkLds<P>;
+    static_assert(MODEL == 0 || P == gp_bwd::DP, "the backward pass runs on 16-row tiles");
+    using L = TrunkLds<P, OdeModel<MODEL>::BWD>;
+    constexpr int NC = OdeModel<MODEL>::NC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double sh[8];
     const int tid = threadIdx.x;
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
     if (row0 >= rend) return;  // padding workgroup of a ragged launch (tables sized for a capacity)
     Rk45State *st = a.st + grp;
     if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
-    const size_t n = (size_t)a.nrows * 9;
+    const size_t n = (size_t)a.nrows * NC;
     const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
     const float *tvec = a.tvec + ((size_t)grp * 8 + slot) * HEADS;
     TrunkPre<P> pre;
@@ -128,13 +143,13 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
     for (int e = tid; e < P * 16; e += TrunkCfg<P>::NT) {
         const int rr = e >> 4, j = e & 15;
         float *xr = lds + rr * L::LD0;
-        if (j >= POSE) {
+        if (j >= NC) {
             xr[j] = 0.f;
             continue;
         }
         const bool live = row0 + rr < rend;
         const int r = live ? row0 + rr : rend - 1;  // rows past the end: clamped duplicates (computed, never stored)
-        const size_t ge = (size_t)r * 9 + j;
+        const size_t ge = (size_t)r * NC + j;
         const bool commit = STAGE == 1 && st->last_accepted;
         double yv = commit ? a.ynew[ge] : a.y[ge];
         if (commit && live) {
@@ -154,19 +169,28 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
         } else if (STAGE == 7) {
             yv = yv + st->h0 * st->direction * a.K[ge];  // common.py: y1 = y0 + h0 * direction * f0
         }
-        xr[j] = (float)yv;  // torch.tensor(x, dtype=float32) (samplers.py:191)
+        xr[j] = j < POSE ? (float)yv : 0.f;  // torch.tensor(x, dtype=float32) (samplers.py:191); the log-density component is no network input
     }
+    if (MODEL == 2) gp_bwd::load_probe_tile(lds, a.probe, row0, rend);
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre);
-    const float *F = lds + L::OFF_H1;
+    // right-hand side per (row, component): F[r * ldf + j]
+    const float *F;
+    int ldf;
+    if constexpr (MODEL == 0) {
+        trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre);
+        F = lds + L::OFF_H1, ldf = L::LDH;
+    } else {
+        F = gp_bwd::score_vjp_tile<MODEL == 1 ? gp_bwd::ENERGY : gp_bwd::SCORE_DIV>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre, sigma);
+        ldf = gp_bwd::LDS_OUT;
+    }
     double *Kout = a.K + (size_t)(STAGE == 7 ? 1 : (STAGE == 0 ? 0 : (STAGE == 6 ? 6 : STAGE))) * n;
     double acc0 = 0.0, acc1 = 0.0;
-    for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
-        const int r = e / POSE, j = e - r * POSE;
+    for (int e = tid; e < P * NC; e += TrunkCfg<P>::NT) {
+        const int r = e / NC, j = e - r * NC;
         if (row0 + r >= rend) continue;
-        const size_t ge = (size_t)(row0 + r) * 9 + j;
-        const float score = F[r * L::LDH + j] / (sigma + 1e-7f);
-        const double kv = 0.0 - (0.5 * g2) * (double)score;  // drift - 0.5 * g^2 * score (samplers.py:198)
+        const size_t ge = (size_t)(row0 + r) * NC + j;
+        const float rhs = MODEL == 0 ? F[r * ldf + j] / (sigma + 1e-7f) : F[r * ldf + j];  // score component (j = 9: divergence estimate)
+        const double kv = 0.0 - (0.5 * g2) * (double)rhs;  // drift - 0.5 * g^2 * score (samplers.py:198; :83-86 for the log-density)
         Kout[ge] = kv;
         if (STAGE == 0) {
             const double yv = a.y[ge];
@@ -238,7 +262,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
         if (threadIdx.x == 0) st->status = 1;
         return;
     }
-    const double nn = (double)grows * 9.0;
+    const double nn = (double)grows * (double)a.ncomp;  // size of the state vector the RMS norms run over
     if (mode == 0) {
         const double s0 = sum_partials(part, nblk, sh);
         const double s1 = sum_partials(part + a.nblocks, nblk, sh);
@@ -317,10 +341,10 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
 __global__ void rk45_record_kernel(OdeArgs a) {
     const Rk45State *st = a.st + blockIdx.y;  // grid (64, ngroups): every group records its own rows at its own slot
     if (!a.traj || !st->last_accepted || st->status < 0) return;
-    const size_t n = (size_t)a.nrows * 9;
+    const size_t n = (size_t)a.nrows * a.ncomp;
     const size_t g_row0 = a.grp_info ? a.grp_info[4 * blockIdx.y + 3] : (size_t)blockIdx.y * a.rows_per_group;
     const size_t g_rows = a.grp_info ? a.grp_info[4 * blockIdx.y + 2] : a.rows_per_group;
-    const size_t e_lo = g_row0 * 9, e_hi = e_lo + g_rows * 9;
+    const size_t e_lo = g_row0 * a.ncomp, e_hi = e_lo + g_rows * a.ncomp;
     if (g_rows == 0) return;
     if (st->n_eval > 0) {
         // 4th-order dense output of the step just accepted (rk.py RkDenseOutput): y(t) = y_old + h * Q . [x, x^2, x^3, x^4],
@@ -352,9 +376,9 @@ __global__ void rk45_record_kernel(OdeArgs a) {
 }
 
 // Denoise (samplers.py:209-218) + normalize_rotation + centre (:224-226); also post-processes the trajectory.
-template <int P>
+template <int P, int MODEL>
 __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a, gp_scorenet net, double denoise_scale, int do_denoise, double *x_out) {
-    using L = TrunkLds<P>;
+    using L = TrunkLds<P, OdeModel<MODEL>::BWD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     int grp, row0, rend;
@@ -365,6 +389,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
     const float *tvec = a.tvec + (size_t)grp * 8 * HEADS;  // slot 0 = eps
     TrunkPre<P> pre;
     trunk_begin<P>(net, pre, a.cvec, tvec, row0, rend, a.kcand);
+    const float sigma = st->stage_sigma[0];
     if (tid < P) {
         const int r = row0 + tid < rend ? row0 + tid : rend - 1;
         float *xr = lds + tid * L::LD0;
@@ -374,9 +399,15 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
         for (int j = 9; j < 16; ++j) xr[j] = 0.f;
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre);
-    const float sigma = st->stage_sigma[0];
-    const float *F = lds + L::OFF_H1;
+    const float *F;
+    int ldf;
+    if constexpr (MODEL == 0) {
+        trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre);
+        F = lds + L::OFF_H1, ldf = L::LDH;
+    } else {
+        F = gp_bwd::score_vjp_tile<gp_bwd::ENERGY>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre, sigma);
+        ldf = gp_bwd::LDS_OUT;
+    }
     if (tid < P && row0 + tid < rend) {
         const int r = row0 + tid;
         double xv[9];
@@ -384,7 +415,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
         const float g = sigma * 4.1272735595703125f;  // (float)sqrt(2*(ln 50 - ln 0.01))
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            const float grad = F[tid * L::LDH + j] / (sigma + 1e-7f);
+            const float grad = MODEL == 0 ? F[tid * ldf + j] / (sigma + 1e-7f) : F[tid * ldf + j];
             const float drift = 0.f - (g * g) * grad;                    // R-SDE sign as written (:216)
             const float dx = drift * (float)denoise_scale;               // f32 tensor * python float stays f32
             xv[j] = yfin[(size_t)r * 9 + j] + (do_denoise ? (double)dx : 0.0);
@@ -396,6 +427,15 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
 #pragma unroll
         for (int j = 0; j < 9; ++j) x_out[(size_t)r * 9 + j] = xv[j];
     }
+}
+
+// likelihood ODE: the final state [R][10] (pose at t = 1 and the accumulated log-density change) as it is
+__global__ void rk45_copy_final_kernel(OdeArgs a, double *x_out) {
+    const size_t g_row0 = (size_t)blockIdx.y * a.rows_per_group;
+    const Rk45State *st = a.st + blockIdx.y;
+    const double *yfin = st->last_accepted ? a.ynew : a.y;
+    const size_t e_lo = g_row0 * a.ncomp, e_hi = e_lo + (size_t)a.rows_per_group * a.ncomp;
+    for (size_t e = e_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_hi; e += (size_t)gridDim.x * blockDim.x) x_out[e] = yfin[e];
 }
 
 // normalize_rotation + centre on every recorded state (samplers.py:220-224)
@@ -455,43 +495,45 @@ int set_lds_attr(K kern, size_t lds) {
 
 }  // namespace
 
-template <int P>
+template <int P, int MODEL>
 static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double *traj, int traj_cap, double t0, double t_bound, double rtol,
                            double atol, double denoise_scale, int do_denoise, int nstates, const float *centre, double *x_out, hipStream_t st) {
     const double *y = a.y;
-    const size_t lds = trunk_lds_bytes<P>();
+    const size_t lds = MODEL == 0 ? trunk_lds_bytes<P>() : gp_bwd::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        if (set_lds_attr(rk45_stage_kernel<P, 0>, lds) || set_lds_attr(rk45_stage_kernel<P, 1>, lds) ||
-            set_lds_attr(rk45_stage_kernel<P, 2>, lds) || set_lds_attr(rk45_stage_kernel<P, 3>, lds) ||
-            set_lds_attr(rk45_stage_kernel<P, 4>, lds) || set_lds_attr(rk45_stage_kernel<P, 5>, lds) ||
-            set_lds_attr(rk45_stage_kernel<P, 6>, lds) || set_lds_attr(rk45_stage_kernel<P, 7>, lds) ||
-            set_lds_attr(rk45_finish_kernel<P>, lds))
+        if (set_lds_attr(rk45_stage_kernel<P, 0, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 1, MODEL>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 2, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 3, MODEL>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 4, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 5, MODEL>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 6, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 7, MODEL>, lds))
             return GP_ELAUNCH;
+        if constexpr (MODEL != 2) {
+            if (set_lds_attr(rk45_finish_kernel<P, MODEL>, lds)) return GP_ELAUNCH;
+        }
         attr_done = true;
     }
     const dim3 grid(a.nblocks), blk(TrunkCfg<P>::NT), blk1(256);
-    const size_t n = (size_t)a.nrows * 9;
+    const size_t n = (size_t)a.nrows * a.ncomp;
     switch (phase) {
         case 0:
             hipLaunchKernelGGL(rk45_reset_kernel, dim3(a.ngroups), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
             if (traj && hipMemcpyAsync(traj, y, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return GP_ELAUNCH;
             break;
         case 1:
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 0>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 0, MODEL>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 0);
             break;
         case 2:
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 7>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 7, MODEL>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
             break;
         case 3:
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 1>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 2>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 3>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 4>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 5>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 6>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 1, MODEL>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 2, MODEL>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 3, MODEL>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 4, MODEL>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 5, MODEL>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, 6, MODEL>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
             if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64, a.ngroups), blk1, 0, st, a);
             break;
@@ -500,9 +542,13 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             break;
         case 5:
             if (!x_out) return GP_EINVAL;
-            hipLaunchKernelGGL((rk45_finish_kernel<P>), grid, blk, lds, st, a, *net, denoise_scale, do_denoise, x_out);
-            if (traj && nstates > 0)
-                hipLaunchKernelGGL(rk45_traj_post_kernel, dim3(128), blk1, 0, st, a.nrows, a.kcand, nstates, centre, traj);
+            if constexpr (MODEL == 2) {
+                hipLaunchKernelGGL(rk45_copy_final_kernel, dim3(32, a.ngroups), blk1, 0, st, a, x_out);
+            } else {
+                hipLaunchKernelGGL((rk45_finish_kernel<P, MODEL>), grid, blk, lds, st, a, *net, denoise_scale, do_denoise, x_out);
+                if (traj && nstates > 0)
+                    hipLaunchKernelGGL(rk45_traj_post_kernel, dim3(128), blk1, 0, st, a.nrows, a.kcand, nstates, centre, traj);
+            }
             break;
         default:
             return GP_EINVAL;
@@ -550,11 +596,12 @@ int gp_rk45_state_layout(int64_t *out, int n) {
     return GP_OK;
 }
 
-static int ode_args(OdeArgs *a, int *tile, int ngroups, int nclouds_per_group, int k, const float *cvec, const float *tvec, const float *centre,
-                    void *state, double *y, double *ynew, double *K, double *partials, double *traj, float *x32) {
+static int ode_args(OdeArgs *a, int *tile, int model, const float *probe, int ngroups, int nclouds_per_group, int k, const float *cvec, const float *tvec,
+                    const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, float *x32) {
     if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || !cvec || !tvec || !centre || !state || !y || !ynew || !K || !partials) return GP_EINVAL;
+    if (model < 0 || model > 2 || (model == 2 && !probe)) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
-    int P = score_tile_rows(ngroups * rg);
+    int P = model == 0 ? score_tile_rows(ngroups * rg) : 16;
     if (ngroups > 1 && rg % P != 0) P = 16;  // tiles must not straddle groups
     if (ngroups > 1 && rg % P != 0) return GP_EINVAL;
     a->nrows = ngroups * rg, a->kcand = k;
@@ -562,6 +609,7 @@ static int ode_args(OdeArgs *a, int *tile, int ngroups, int nclouds_per_group, i
     a->blk_info = nullptr, a->grp_info = nullptr;
     a->cvec = cvec, a->tvec = tvec, a->centre = centre, a->st = (Rk45State *)state;
     a->y = y, a->ynew = ynew, a->K = K, a->partials = partials, a->traj = traj, a->x32 = x32;
+    a->probe = probe, a->ncomp = model == 2 ? 10 : 9;
     *tile = P;
     return GP_OK;
 }
@@ -579,18 +627,29 @@ static int ode_args(OdeArgs *a, int *tile, int ngroups, int nclouds_per_group, i
  * step controllers - error norm, accept / reject, step size per group, exactly as separate solve_ivp calls - and share every
  * launch; a finished group's workgroups exit at once.  state: ngroups * gp_rk45_state_bytes(); tvec [ngroups][8][768];
  * partials [3][nblocks], nblocks = ngroups * ceil(rows_per_group / tile), tile from gp_pc_tile_rows. */
+int gp_rk45_phase_model(int model, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
+                        const float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
+                        int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
+                        double *x_out, gp_stream_t s) {
+    OdeArgs a;
+    int P = 0;
+    int rc = ode_args(&a, &P, model, probe, ngroups, nclouds_per_group, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
+    if (rc != GP_OK || !net) return GP_EINVAL;
+    if (model != 0 && (!net->w_headx_t || !net->w_pose2_t || !net->w_pose0_t)) return GP_EINVAL;
+#define GP_RK45_CALL(PP, MM) \
+    rk45_phase_impl<PP, MM>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out, (hipStream_t)s)
+    if (model == 1) return GP_RK45_CALL(16, 1);
+    if (model == 2) return GP_RK45_CALL(16, 2);
+    return P == 16 ? GP_RK45_CALL(16, 0) : GP_RK45_CALL(32, 0);
+#undef GP_RK45_CALL
+}
+
 int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, const float *tvec,
                           const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
                           double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                           gp_stream_t s) {
-    OdeArgs a;
-    int P = 0;
-    int rc = ode_args(&a, &P, ngroups, nclouds_per_group, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
-    if (rc != GP_OK || !net) return GP_EINVAL;
-    return P == 16 ? rk45_phase_impl<16>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
-                                         (hipStream_t)s)
-                   : rk45_phase_impl<32>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
-                                         (hipStream_t)s);
+    return gp_rk45_phase_model(0, nullptr, phase, ngroups, nclouds_per_group, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap, t0,
+                               t_bound, rtol, atol, denoise_scale, do_denoise, nstates, x_out, s);
 }
 
 int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nblocks, const int32_t *blk_info, int tile, int nclouds_total, int k,
@@ -606,10 +665,11 @@ int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nb
     a.blk_info = blk_info, a.grp_info = grp_info;
     a.cvec = cvec, a.tvec = tvec, a.centre = centre, a.st = (Rk45State *)state;
     a.y = y, a.ynew = ynew, a.K = K, a.partials = partials, a.traj = traj, a.x32 = nullptr;
-    return tile == 16 ? rk45_phase_impl<16>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
-                                            (hipStream_t)s)
-                      : rk45_phase_impl<32>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
-                                            (hipStream_t)s);
+    a.probe = nullptr, a.ncomp = 9;
+    return tile == 16 ? rk45_phase_impl<16, 0>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                               (hipStream_t)s)
+                      : rk45_phase_impl<32, 0>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                               (hipStream_t)s);
 }
 
 int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state,

@@ -8,6 +8,7 @@
 //                + W1x . pose_feat (per row, per evaluation: here, on fp32 MFMA)
 // The three heads are stacked into one 768-wide layer; their 256->3 output layers are applied in the
 // accumulator epilogue (no 768-wide activation ever reaches LDS).
+#include "score_bwd.h"
 #include "trunk_chain.h"
 
 namespace {
@@ -176,9 +177,13 @@ struct PcArgs {
 //                using score_{i-1} and the batch-mean gradient norm reduced from every block's partial sum
 //   i < nsteps : evaluate score_i = s(x_i, t_i) and write this block's partial sum of |score_i|_2
 //   i == nsteps: (finish only) also post-process mean_x (:157-158)
-template <int P>
+// MODEL 0: the score network (score = f / (sigma + 1e-7), scorenet.py:217).  MODEL 1: the ENERGY network, whose score is the
+// gradient of its inner-product energy (energynet.py:200-222): forward + vector-Jacobian product in the tile (score_bwd.h), 16-row
+// tiles only.  The same kernel otherwise: sampling from the energy model is the same captured launch chain.
+template <int P, int MODEL>
 __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_scorenet net) {
-    using L = TrunkLds<P>;
+    static_assert(MODEL == 0 || P == gp_bwd::DP, "the backward pass runs on 16-row tiles");
+    using L = TrunkLds<P, MODEL == 1>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_gn;
     const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
@@ -254,13 +259,24 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         load_x_tile<P>(lds, a.x, row0, a.nrows);
     }
     __syncthreads();
-    trunk_ftheta<P>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre);
-    float *F = lds + L::OFF_H1;
-    for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
-        const int r = e / POSE, j = e - r * POSE;
-        const float v = F[r * L::LDH + j] / (sigma + 1e-7f);
-        F[r * L::LDH + j] = v;
-        if (row0 + r < a.nrows) a.score[(size_t)(row0 + r) * POSE + j] = v;
+    float *F;
+    int ldf;
+    if constexpr (MODEL == 0) {
+        trunk_ftheta<P>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre);
+        F = lds + L::OFF_H1, ldf = L::LDH;
+        for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
+            const int r = e / POSE, j = e - r * POSE;
+            const float v = F[r * ldf + j] / (sigma + 1e-7f);
+            F[r * ldf + j] = v;
+            if (row0 + r < a.nrows) a.score[(size_t)(row0 + r) * POSE + j] = v;
+        }
+    } else {
+        F = const_cast<float *>(gp_bwd::score_vjp_tile<gp_bwd::ENERGY>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre, sigma));
+        ldf = gp_bwd::LDS_OUT;
+        for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
+            const int r = e / POSE, j = e - r * POSE;
+            if (row0 + r < a.nrows) a.score[(size_t)(row0 + r) * POSE + j] = F[r * ldf + j];
+        }
     }
     __syncthreads();
     if (tid < 64) {
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
             if (row0 + r < a.nrows) {
                 float q = 0.f;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) q += F[r * L::LDH + j] * F[r * L::LDH + j];
+                for (int j = 0; j < 9; ++j) q += F[r * ldf + j] * F[r * ldf + j];
                 s += sqrtf(q);
             }
         }
@@ -489,10 +505,14 @@ int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k) {
 static int pc_rows_per_partial(int P) { return P == 16 || P == 32 ? P : P / gp_chain::NW; }  // tile form: per workgroup; chain form: per wave
 static int pc_rows_per_wg(int P) { return P; }
 
-int gp_pc_layout(int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out) {
-    if (ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || !tile_out || !nparts_out) return GP_EINVAL;
+int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out) {
+    if ((model != 0 && model != 1) || ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || !tile_out || !nparts_out) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
     int P = tile;
+    if (model == 1) {  // the energy model's score needs the backward pass: 16-row tiles
+        if (P != 0 && P != 16) return GP_EINVAL;
+        P = 16;
+    }
     if (P == 0) P = score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
     if (P != 16 && P != 32 && P != 128) return GP_EINVAL;
     if (P == 128 && !gp_chain::Cfg<2>::fits(k)) return GP_EINVAL;
@@ -503,7 +523,7 @@ int gp_pc_layout(int tile, int ngroups, int nclouds_per_group, int k, int *tile_
     return GP_OK;
 }
 
-int gp_pc_step_plan(int tile, int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                     const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x,
                     float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
     if (ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || step < 0 || step > nsteps || !net || !cvec || !tvec_all || !sched || !z_langevin ||
@@ -512,8 +532,9 @@ int gp_pc_step_plan(int tile, int ngroups, int nclouds_per_group, int k, int ste
     const int rg = nclouds_per_group * k, R = ngroups * rg;
     if (R == 0) return GP_OK;
     int P = 0, nparts = 0;
-    const int rc = gp_pc_layout(tile, ngroups, nclouds_per_group, k, &P, &nparts);
+    const int rc = gp_pc_layout(model, tile, ngroups, nclouds_per_group, k, &P, &nparts);
     if (rc != GP_OK) return rc;
+    if (model == 1 && (!net->w_headx_t || !net->w_pose2_t || !net->w_pose0_t)) return GP_EINVAL;
     PcArgs a;
     a.nrows = R, a.kcand = k, a.step = step, a.nsteps = nsteps;
     a.nparts = nparts, a.ppg = nparts / ngroups, a.rows_per_group = rg;
@@ -526,34 +547,38 @@ int gp_pc_step_plan(int tile, int ngroups, int nclouds_per_group, int k, int ste
     if (P == 128) return launch_pc_chain<2>(a, net, nwg, st);
     static bool attr_done = false;
     if (!attr_done) {
-        if (set_lds(pc_step_kernel<16>, trunk_lds_bytes<16>()) || set_lds(pc_step_kernel<32>, trunk_lds_bytes<32>())) return GP_ELAUNCH;
+        if (set_lds(pc_step_kernel<16, 0>, trunk_lds_bytes<16>()) || set_lds(pc_step_kernel<32, 0>, trunk_lds_bytes<32>()) ||
+            set_lds(pc_step_kernel<16, 1>, gp_bwd::LDS_BYTES))
+            return GP_ELAUNCH;
         attr_done = true;
     }
-    if (P == 16)
-        hipLaunchKernelGGL(pc_step_kernel<16>, dim3(nwg), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), st, a, *net);
+    if (model == 1)
+        hipLaunchKernelGGL((pc_step_kernel<16, 1>), dim3(nwg), dim3(TrunkCfg<16>::NT), gp_bwd::LDS_BYTES, st, a, *net);
+    else if (P == 16)
+        hipLaunchKernelGGL((pc_step_kernel<16, 0>), dim3(nwg), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), st, a, *net);
     else
-        hipLaunchKernelGGL(pc_step_kernel<32>, dim3(nwg), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), st, a, *net);
+        hipLaunchKernelGGL((pc_step_kernel<32, 0>), dim3(nwg), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), st, a, *net);
     return gp_launch_status();
 }
 
 int gp_pc_step_coupled(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
                        float *x, float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
-    return gp_pc_step_plan(0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
+    return gp_pc_step_plan(0, 0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
                            partials, traj, gn_ext, s);
 }
 
 int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
                        float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s) {
-    return gp_pc_step_plan(0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
+    return gp_pc_step_plan(0, 0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
                            partials, traj, nullptr, s);
 }
 
 int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec, const float *tvec_all,
                const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
                float *score, float *partials, float *traj, gp_stream_t s) {
-    return gp_pc_step_plan(0, 1, nclouds, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score, partials, traj,
+    return gp_pc_step_plan(0, 0, 1, nclouds, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score, partials, traj,
                            nullptr, s);
 }
 

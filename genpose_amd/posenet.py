@@ -146,24 +146,35 @@ class GFObjectPose:
 
     def _sample_energy_model(self, cvec, K, centre, sampler, init_x, T0, noise, return_process):
         """Sampling from the ENERGY model: the score is the autograd gradient of the inner-product energy (posenet.py:94-130
-        with self = PoseEnergyNet, energynet.py:200-222), evaluated by gp_energy_score - never f/sigma.  Secondary path, see
-        genpose_amd/energy_sampling.py."""
-        from . import energy_sampling as es
+        with self = PoseEnergyNet, energynet.py:200-222) - never f/sigma.  The same device-resident samplers as the score model's
+        (one captured launch chain for PC, the RK45 driver for the ODE), with the forward pass + vector-Jacobian product of the energy
+        network inside the step / stage kernels (csrc/score_bwd.h)."""
         R = cvec.shape[0] * K
         if sampler == "pc":
             n = self.cfg.sampling_steps
             if n is None:
                 raise ValueError("the PC sampler needs cfg.sampling_steps")
             x0 = self._prior_to_device((R, 9)) if init_x is None else init_x.float()
+            B = cvec.shape[0]
+            key = ("pc-energy", B, K, n, return_process)
+            smp = self._samplers.get(key)
+            if smp is None:  # the same captured launch chain as the score model's, with the energy model's score inside the step kernel
+                smp = self._samplers[key] = PCSampler(self.pose_score_net, B, K, n, self.device, record_traj=return_process, model="energy")
             z1, z2 = noise if noise is not None else (None, None)
-            return es.energy_pc_sample(self.pose_score_net, cvec, K, centre, x0, n, z1, z2, eps=self.sampling_eps, return_process=return_process)
+            xs, res = smp.run(cvec, centre, x0, z1, z2)
+            return (xs.clone() if xs is not None else None), res.clone()
         if sampler == "ode":
             T0 = self.T if T0 is None else T0
             pr = self._prior_to_device((R, 9), T=T0)
             x0 = pr if init_x is None else init_x.float() + pr
-            self.last_energy_ode_stats = {}
-            return es.energy_ode_sample(self.pose_score_net, cvec, K, centre, x0, T0, num_steps=self.cfg.sampling_steps, eps=self.sampling_eps,
-                                        return_process=return_process, stats=self.last_energy_ode_stats)
+            B = cvec.shape[0]
+            key = ("ode-energy", B, K)
+            smp = self._samplers.get(key)
+            if smp is None:  # the device-resident RK45 driver with the energy model's score inside the stage kernels
+                smp = self._samplers[key] = ODESampler(self.pose_score_net, B, K, self.device, model="energy")
+            out = smp.run(cvec, centre, x0, T0, num_steps=self.cfg.sampling_steps, eps=self.sampling_eps, return_process=return_process)
+            self.last_energy_ode_stats = {"nfev": int(smp.last_stats["nfev"]), "attempts": int(smp.last_stats["n_attempts"])}
+            return out
         raise NotImplementedError(sampler)
 
     def calc_likelihood(self, data, atol=1e-5, rtol=1e-5):
@@ -177,8 +188,12 @@ class GFObjectPose:
         x = data["sampled_pose"].float().contiguous()
         epsilon = self.prior_fn((x.shape[0], 9)).to(self.device)
         self.last_likelihood_stats = {}
+        key = ("likelihood", cvec.shape[0], K)
+        solver = self._samplers.get(key)
+        if solver is None:
+            solver = self._samplers[key] = ODESampler(self.pose_score_net, cvec.shape[0], K, self.device, model="likelihood")
         _, ll = cond_ode_likelihood(self.pose_score_net, cvec, K, x, epsilon, eps=self.sampling_eps, rtol=rtol, atol=atol,
-                                    stats=self.last_likelihood_stats)
+                                    stats=self.last_likelihood_stats, solver=solver)
         return ll
 
     @staticmethod

@@ -25,7 +25,7 @@ def pc_schedule(num_steps, eps=EPS):
 class PCSampler:
     """Predictor-corrector sampler state for a fixed (B, K, num_steps): buffers + optional hipGraph of the whole loop."""
 
-    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1, coupling_group=None, tile=0):
+    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1, coupling_group=None, tile=0, model="score"):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: one launch chain serves all of
         them, the batch-mean gradient norm (samplers.py:130-132) stays per batch (gp_pc_step_grouped).
 
@@ -36,6 +36,11 @@ class PCSampler:
         all-reduce sits between consecutive launches), not as one captured graph."""
         if B % groups:
             raise ValueError(f"{B} clouds do not split into {groups} equal batches")
+        if model not in ("score", "energy"):
+            raise ValueError(model)
+        # model 'energy': `net` holds the ENERGY network's weights and the sampler is driven by ITS score - the gradient of the
+        # inner-product energy (posenet.py:94-130 on a PoseEnergyNet), evaluated inside the step kernel (forward + vector-Jacobian product)
+        self.model = 0 if model == "score" else 1
         self.net, self.B, self.K, self.n, self.groups = net, B, K, num_steps, groups
         self.dev = torch.device(device)
         R = B * K
@@ -44,11 +49,11 @@ class PCSampler:
         # through an LDS ring) for launches of ~32 000 rows and more; `tile` forces one (tests, measurements)
         import ctypes
         t_out, n_out = ctypes.c_int(0), ctypes.c_int(0)
-        if _lib.lib().gp_pc_layout(int(tile), groups, B // groups, K, ctypes.byref(t_out), ctypes.byref(n_out)) != 0:
+        if _lib.lib().gp_pc_layout(self.model, int(tile), groups, B // groups, K, ctypes.byref(t_out), ctypes.byref(n_out)) != 0:
             raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                              "run the batches separately")
         self.tile, self.nparts = t_out.value, n_out.value
-        self.kernel_name = f"pc_step_kernel<{self.tile}>" if self.tile in (16, 32) else \
+        self.kernel_name = f"pc_step_kernel<{self.tile},{self.model}>" if self.tile in (16, 32) else \
             "pc_step_chain_kernel<2>"
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)
@@ -72,7 +77,7 @@ class PCSampler:
 
     def launch_step(self, i):
         """Launch i of the chain (0 <= i <= n) on the current stream: finishes step i-1 and, for i < n, evaluates the score at t_i."""
-        _lib.call("gp_pc_step_plan", self.tile, self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
+        _lib.call("gp_pc_step_plan", self.model, self.tile, self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
                   ptr(self.sched), ptr(self.z1), ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
                   ptr(self.traj), ptr(self.gn_ext), stream_ptr())
 
@@ -143,11 +148,21 @@ class ODESampler:
     TRAJ_CAP = 192
     CHUNKS = (8, 12, 16, 24, 32, 40, 48, 64, 80, 96, 128)  # attempts per first replay
 
-    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None):
+    MODELS = {"score": 0, "energy": 1, "likelihood": 2}
+
+    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None, model="score"):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: every batch keeps its own adaptive
         step control (error norm over ITS rows, accept / reject, step size - what separate cond_ode_sampler calls would do) while
-        all of them share each launch (gp_rk45_phase_grouped)."""
+        all of them share each launch (gp_rk45_phase_grouped).
+
+        model: what the driver integrates (gp_rk45_phase_model) - 'score' the probability-flow ODE of the score network; 'energy' the
+        same ODE with the ENERGY network's score (`net` holds its weights; forward + vector-Jacobian product inside the stage
+        kernels); 'likelihood' the [pose, log-density] ODE of cond_ode_likelihood (run_likelihood)."""
+        self.model = self.MODELS[model]
+        self.ncomp = 10 if self.model == 2 else 9
         self.ragged = group_clouds is not None
+        if self.ragged and self.model != 0:
+            raise NotImplementedError("ragged groups integrate the score network's ODE only")
         self.dev = torch.device(device)
         if self.ragged:
             # groups of different sizes (tracking: the objects of one frame): consecutive cloud ranges, tiles that end at the group
@@ -164,8 +179,8 @@ class ODESampler:
         self.net, self.B, self.K, self.groups = net, B, K, groups
         R = self.R = B * K
         if not self.ragged:
-            self.tile = _lib.lib().gp_pc_tile_rows(groups, B // groups, K)
-            if self.tile < 0:
+            self.tile = _lib.lib().gp_pc_tile_rows(groups, B // groups, K) if self.model == 0 else 16  # the backward pass runs on 16-row tiles
+            if self.tile < 0 or (groups > 1 and (R // groups) % self.tile):
                 raise ValueError(f"{B // groups} clouds x {K} candidates per batch is not a multiple of the 16-row tile; run the batches separately")
             self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
         if self.ragged:
@@ -174,13 +189,17 @@ class ODESampler:
         self.state_bytes = nbytes
         self.state = torch.zeros(groups * nbytes, dtype=torch.uint8, device=self.dev)
         d = lambda *s: torch.zeros(*s, dtype=torch.float64, device=self.dev)
-        self.y, self.ynew, self.Kbuf = d(R * 9), d(R * 9), d(7, R * 9)
+        nc = self.ncomp
+        self.y, self.ynew, self.Kbuf = d(R * nc), d(R * nc), d(7, R * nc)
         self.partials = d(3, self.nblocks)
-        self.x_out = d(R, 9)
+        self.x_out = d(R, nc)
+        self.probe = torch.zeros(R, 9, device=self.dev) if self.model == 2 else None
         self.tvec = torch.zeros(groups * 8, 768, device=self.dev)
         self.cvec = torch.empty(B, 768, device=self.dev)
         self.centre = torch.empty(B, 3, device=self.dev)
         self.traj = None
+        if self.model == 2 and poll == 8:
+            poll = 64  # the likelihood ODE runs from eps to 1 at rtol 1e-5: thousands of attempts, fewer status reads
         self.use_graph, self.poll = use_graph, poll
         self._graphs = {}        # kind ('graph' | 'graph_traj' | 'graph_dense') -> {attempts per replay: captured graph}
         self._attempt_hist = {}  # (kind, T0) -> attempts the previous solve took
@@ -228,7 +247,7 @@ class ODESampler:
             _lib.call("gp_rk45_phase_ragged", phase, self.groups, ptr(self.grp_info), self.nblocks, ptr(self.blk_info), self.tile, self.B, self.K,
                       self.net.w.ref(), *tail)
         else:
-            _lib.call("gp_rk45_phase_grouped", phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail)
+            _lib.call("gp_rk45_phase_model", self.model, ptr(self.probe), phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail)
 
     def _embed(self):
         import ctypes
@@ -260,10 +279,81 @@ class ODESampler:
         st["log_acc"] = g("log_acc", np.int32, 512)[:na].copy()
         return st
 
+    def _solve(self, traj, gname, T0, max_attempts=4096):
+        """The adaptive loop after phases 0-2: replays captured attempts until every group's device-side status word is set.
+        Returns the per-group states."""
+        n_done = 0
+        # The attempt count is data dependent (scipy's controller), but it barely moves between solves of the same kind (same T0, same
+        # kind of clouds), and an attempt launched on a FINISHED solve exits at once.  So the first replay is a graph sized for the
+        # previous solve's attempt count (+ margin): in the common case the whole adaptive loop is ONE graph replay and one status
+        # read; a solve that needs more continues in chunks of `poll` attempts.
+        hist_key = (gname, round(float(T0), 3))
+        expect = self._attempt_hist.get(hist_key)
+        first = self.poll if expect is None else next((c for c in self.CHUNKS if c >= expect + 2), self.CHUNKS[-1])
+        while True:
+            chunk = first if n_done == 0 else self.poll
+            if self.use_graph:
+                graphs = self._graphs.setdefault(gname, {})
+                if chunk not in graphs:
+                    if not graphs:
+                        self._attempt(traj)  # warm-up outside capture
+                        n_done += 1
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for _ in range(chunk):
+                            self._attempt(traj)
+                    graphs[chunk] = g
+                graphs[chunk].replay()
+            else:
+                for _ in range(chunk):
+                    self._attempt(traj)
+            n_done += chunk
+            sts = self._read_states()
+            if self.ragged:
+                sts = sts[: len(self.group_clouds)]
+            if all(s_["status"] != 0 for s_ in sts):
+                break
+            if n_done >= max_attempts:
+                raise RuntimeError("ODE sampler: attempt budget exhausted")
+        if any(s_["status"] < 0 for s_ in sts):
+            raise RuntimeError("ODE sampler: required step size is less than spacing between numbers (scipy TOO_SMALL_STEP)")
+        self.group_stats = sts
+        self._attempt_hist[hist_key] = max(int(s_["n_attempts"]) for s_ in sts)
+        self.last_replays = {"first_chunk": first, "attempts_launched": n_done}
+        return sts
+
+    def run_likelihood(self, cvec, x, probe, eps=EPS, rtol=1e-5, atol=1e-5, max_attempts=16384):
+        """cond_ode_likelihood's integration (samplers.py:73-93) on the device: state [x, logp] from t = eps to t = 1 with the fixed
+        Hutchinson probe.  cvec [B,768]; x, probe [B*K,9].  Returns (z [R,9] f64, delta_logp [R] f64); evaluation count in
+        last_stats['nfev'] (2 for the initial step + 6 per attempt, like solve_ivp)."""
+        if self.model != 2:
+            raise RuntimeError("ODESampler(model='likelihood') required")
+        R = self.R
+        if cvec.shape[0] != self.B or x.shape[0] != R or probe.shape[0] != R:
+            raise ValueError(f"likelihood solver set up for {self.B} clouds x {self.K} rows got {cvec.shape[0]} clouds / {x.shape[0]} rows")
+        self.cvec.copy_(cvec)
+        self.centre.zero_()
+        self.probe.copy_(probe.float())
+        y0 = self.y.view(R, 10)
+        y0[:, :9].copy_(x.double())   # solve_ivp casts the initial state to float64
+        y0[:, 9].zero_()
+        self._phase(0, None, t0=eps, t_bound=1.0, rtol=rtol, atol=atol)
+        self._embed()
+        self._phase(1, None)
+        self._embed()
+        self._phase(2, None)
+        sts = self._solve(None, "graph", eps, max_attempts)
+        self._phase(5, None)
+        self.last_stats = sts[0]
+        out = self.x_out.clone()
+        return out[:, :9], out[:, 9]
+
     def run(self, cvec, centre, init_x, T0, num_steps=None, eps=EPS, rtol=1e-5, atol=1e-5, denoise=True, return_process=False,
             max_attempts=4096):
         """Returns (xs [R,S,9] f64 or None, x [R,9] f64).  With num_steps=None the in-process samples are the accepted
         states (like solve_ivp without t_eval)."""
+        if self.model == 2:
+            raise RuntimeError("ODESampler(model='likelihood') integrates the likelihood ODE: call run_likelihood()")
         dense = return_process and num_steps is not None
         if self.groups > 1 and return_process and not dense:
             raise NotImplementedError("accepted-state trajectories have a different length per batch: ask for them one batch at a time")
@@ -301,46 +391,9 @@ class ODESampler:
         self._phase(1, traj)
         self._embed()
         self._phase(2, traj)
-        n_done = 0
-        # The attempt count is data dependent (scipy's controller), but it barely moves between solves of the same kind (same T0, same
-        # kind of clouds), and an attempt launched on a FINISHED solve exits at once.  So the first replay is a graph sized for the
-        # previous solve's attempt count (+ margin): in the common case the whole adaptive loop is ONE graph replay and one status
-        # read; a solve that needs more continues in chunks of `poll` attempts.
         gname = "graph_dense" if dense else ("graph_traj" if traj is not None else "graph")
-        hist_key = (gname, round(float(T0), 3))
-        expect = self._attempt_hist.get(hist_key)
-        first = self.poll if expect is None else next((c for c in self.CHUNKS if c >= expect + 2), self.CHUNKS[-1])
-        while True:
-            chunk = first if n_done == 0 else self.poll
-            if self.use_graph:
-                graphs = self._graphs.setdefault(gname, {})
-                if chunk not in graphs:
-                    if not graphs:
-                        self._attempt(traj)  # warm-up outside capture
-                        n_done += 1
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        for _ in range(chunk):
-                            self._attempt(traj)
-                    graphs[chunk] = g
-                graphs[chunk].replay()
-            else:
-                for _ in range(chunk):
-                    self._attempt(traj)
-            n_done += chunk
-            sts = self._read_states()
-            if self.ragged:
-                sts = sts[: len(self.group_clouds)]
-            if all(s_["status"] != 0 for s_ in sts):
-                break
-            if n_done >= max_attempts:
-                raise RuntimeError("ODE sampler: attempt budget exhausted")
-        if any(s_["status"] < 0 for s_ in sts):
-            raise RuntimeError("ODE sampler: required step size is less than spacing between numbers (scipy TOO_SMALL_STEP)")
+        sts = self._solve(traj, gname, T0, max_attempts)
         st = sts[0]
-        self.group_stats = sts
-        self._attempt_hist[hist_key] = max(int(s_["n_attempts"]) for s_ in sts)
-        self.last_replays = {"first_chunk": first, "attempts_launched": n_done}
         self._phase(4, traj, t0=eps)
         self._embed()
         nstates = (num_steps if dense else int(st["n_accepted"]) + 1) if traj is not None else 0

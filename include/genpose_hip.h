@@ -217,13 +217,17 @@ int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int 
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor,
                        const float *centre, float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s);
 
-/* Launch plan of the PC sampler for (ngroups x nclouds_per_group clouds x k candidates): tile = 0 asks for the automatic choice, else
+/* Launch plan of the PC sampler for (ngroups x nclouds_per_group clouds x k candidates) and a model (see gp_pc_step_plan): tile = 0 asks for the automatic choice, else
  * 16 / 32 / 128 as in gp_score_eval_plan.  *tile_out = the plan taken, *nparts_out = partial sums of |score| per step
  * (`partials` must hold nsteps * nparts floats: one per workgroup in the tile form, one per wave in the chain form).  GP_EINVAL when a
  * workgroup of the plan would straddle two groups. */
-int gp_pc_layout(int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out);
-/* gp_pc_step_coupled with the plan chosen by the caller (tile as above; 0 = automatic).  Every launch of one chain must use the same plan. */
-int gp_pc_step_plan(int tile, int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
+int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out);
+/* gp_pc_step_coupled with the plan chosen by the caller (tile as above; 0 = automatic; every launch of one chain must use the same
+ * plan) and the MODEL whose score drives the sampler: 0 = the score network (f / (sigma + 1e-7), scorenet.py:217); 1 = the ENERGY
+ * network (`net` = its parameter block): the reference samples from it with the autograd gradient of its inner-product energy
+ * (posenet.py:94-130 with PoseEnergyNet.forward(return_item='score'), energynet.py:200-222) - here the forward pass and the
+ * vector-Jacobian product run inside the step kernel (16-row tiles), so the energy model gets the same one-graph launch chain. */
+int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                     const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x,
                     float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s);
 
@@ -271,6 +275,19 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
                           const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
                           double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                           gp_stream_t s);
+/* The same driver for the three right-hand sides it can integrate (`model`):
+ *   0  gp_rk45_phase_grouped: probability-flow ODE of the score network;
+ *   1  the same ODE driven by the ENERGY network's score, the gradient of its inner-product energy (posenet.py:94-130 on a
+ *      PoseEnergyNet, energynet.py:200-222; `net` = the energy net's block) - forward + vector-Jacobian product inside the stage kernel;
+ *   2  the likelihood ODE of cond_ode_likelihood (samplers.py:22-99): state [R][10] = pose and accumulated log-density change,
+ *      d logp / dt = -g^2/2 probe^T (d score / d x) probe with the fixed Skilling-Hutchinson `probe` [R][9] (device); y, ynew [R*10],
+ *      K [7][R*10]; one error norm over all R*10 components (scipy integrates the concatenated vector); phase 5 copies the final
+ *      state to x_out [R][10] (no denoise / normalisation); phases 4 and the trajectory arguments are unused.
+ * Models 1 and 2 run on 16-row tiles: partials [3][ngroups * ceil(rows_per_group / 16)]. */
+int gp_rk45_phase_model(int model, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
+                        const float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
+                        int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
+                        double *x_out, gp_stream_t s);
 /* Ragged variant: groups with different numbers of clouds (tracking: the objects of one frame form a group, frames of different
  * sequences share the launches).  grp_info [ngroups][4] = {first workgroup, workgroups, rows, first row}; blk_info [nblocks][3] =
  * {group, first row, end row (exclusive) of the group} per workgroup of `tile` (16 or 32) rows; both device int32.  Rows stay

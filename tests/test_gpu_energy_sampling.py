@@ -115,3 +115,84 @@ def test_per_row_times_are_refused_not_truncated():
         agent.net({"pts_feat": feat, "sampled_pose": torch.zeros(6, 9, device="cuda"), "t": t, "_repeat": 3}, mode="energy")
     with pytest.raises(NotImplementedError):
         agent.net({"pts_feat": feat, "sampled_pose": torch.zeros(6, 9, device="cuda"), "t": t, "_repeat": 3}, mode="score")
+
+
+def test_energy_model_samplers_are_device_resident_and_grouped():
+    """The energy model's samplers are the score model's device-resident ones (one captured launch chain / the RK45 driver) with the
+    forward + vector-Jacobian pass inside the kernels: replays are bit-identical, and two batches sharing the launches keep their
+    own batch-global couplings (each equals the oracle's sampler run on it alone)."""
+    import genpose_amd
+    from genpose_amd.samplers import ODESampler, PCSampler
+    from genpose_amd.scorenet import ScoreNetHIP
+    import os
+    assert not os.path.exists(os.path.join(os.path.dirname(genpose_amd.__file__), "energy_sampling.py"))  # the host-driven loops are gone
+    sde = go.make_state_dict(0, "energy")
+    net = ScoreNetHIP(sde, "cuda")
+    G, B1, K, n = 2, 2, 8, 6
+    R1 = B1 * K
+    gen = torch.Generator().manual_seed(21)
+    pf = torch.randn(G * B1, 1024, generator=gen).abs()
+    centre = torch.randn(G * B1, 3, generator=gen) * 0.3
+    init_x = torch.randn(G * R1, 9, generator=gen) * 50.0
+    init_x[R1:] *= 0.3
+    z1, z2 = torch.randn(n, G * R1, 9, generator=gen), torch.randn(n, G * R1, 9, generator=gen)
+    cvec = net.cloud_embed(pf.cuda())
+    smp = PCSampler(net, G * B1, K, n, "cuda", use_graph=True, groups=G, model="energy")
+    assert smp.tile == 16 and smp.kernel_name == "pc_step_kernel<16,1>"
+    outs = []
+    for _ in range(2):
+        _, mean_x = smp.run(cvec, centre.cuda(), init_x.cuda(), z1.cuda(), z2.cuda())
+        torch.cuda.synchronize()
+        outs.append(mean_x.clone())
+    assert torch.equal(outs[0], outs[1]) and smp.graph is not None
+    for g in range(G):
+        rows = slice(g * R1, (g + 1) * R1)
+        feat_rows = pf[g * B1:(g + 1) * B1].repeat_interleave(K, 0)
+        _, ref = go.pc_sampler(lambda x, t: go.energy_score(sde, feat_rows, x, t)[0], init_x[rows], centre[g * B1:(g + 1) * B1].repeat_interleave(K, 0),
+                               n, z1[:, rows], z2[:, rows])
+        got, want = outs[0][rows].cpu().numpy(), ref.numpy()
+        np.testing.assert_allclose(got[:, :6], want[:, :6], rtol=0, atol=2e-3, err_msg=f"batch {g}")
+        np.testing.assert_allclose(got[:, 6:], want[:, 6:], rtol=0, atol=1e-3 * max(1.0, float(np.abs(want[:, 6:]).max())), err_msg=f"batch {g}")
+    with pytest.raises(ValueError):
+        PCSampler(net, 640, 50, n, "cuda", groups=10, model="energy", tile=128)  # the backward pass runs on 16-row tiles
+    # ODE: two batches, each with its own step controller == the oracle's solve of that batch alone (attempt for attempt)
+    T0 = 0.3
+    y0 = torch.randn(G * R1, 9, generator=gen) * float(go.ve_sigma(torch.tensor(T0)))
+    ode = ODESampler(net, G * B1, K, "cuda", groups=G, model="energy")
+    _, x = ode.run(cvec, centre.cuda(), y0.cuda(), T0)
+    for g in range(G):
+        rows = slice(g * R1, (g + 1) * R1)
+        feat_rows = pf[g * B1:(g + 1) * B1].repeat_interleave(K, 0)
+        _, ref, nfev = go.ode_sampler(lambda xx, t: go.energy_score(sde, feat_rows, xx, t)[0], y0[rows], centre[g * B1:(g + 1) * B1].repeat_interleave(K, 0), T0)
+        got = x[rows].cpu().numpy()
+        np.testing.assert_allclose(got[:, :6], ref.numpy()[:, :6], rtol=0, atol=2e-3, err_msg=f"batch {g}")
+        np.testing.assert_allclose(got[:, 6:], ref.numpy()[:, 6:], rtol=0, atol=5e-4 * max(1.0, float(ref[:, 6:].abs().max())), err_msg=f"batch {g}")
+        assert abs(int(ode.group_stats[g]["nfev"]) - nfev) <= max(12, 0.1 * nfev), (g, ode.group_stats[g]["nfev"], nfev)
+
+
+def test_likelihood_rows_per_cloud_and_solver_reuse():
+    """cond_ode_likelihood with several candidates per cloud (the reference repeats the cloud features row by row): the same rows
+    with per-cloud embeddings addressed by row / K and with one embedding per row give the same solve - the error norm runs over the
+    same state vector - and a reused solver (captured attempts) reproduces its own result bit for bit.  (Agreement with the imported
+    reference's solve: fixture G12, tests/test_gpu_sampler.py.)"""
+    from genpose_amd.likelihood import cond_ode_likelihood
+    from genpose_amd.samplers import ODESampler
+    from genpose_amd.scorenet import ScoreNetHIP
+    net = ScoreNetHIP(go.make_state_dict(0, "score"), "cuda")
+    B, K = 2, 3
+    gen = torch.Generator().manual_seed(31)
+    pf = torch.randn(B, 1024, generator=gen).abs().cuda()
+    x = torch.randn(B * K, 9, generator=gen).cuda()
+    probe = (torch.randn(B * K, 9, generator=gen) * 50.0).cuda()
+    cvec = net.cloud_embed(pf)
+    solver = ODESampler(net, B, K, "cuda", model="likelihood")
+    s1, s2, s3 = {}, {}, {}
+    z1, l1 = cond_ode_likelihood(net, cvec, K, x, probe, rtol=1e-4, atol=1e-4, stats=s1, solver=solver)
+    z2, l2 = cond_ode_likelihood(net, cvec, K, x, probe, rtol=1e-4, atol=1e-4, stats=s2, solver=solver)
+    z3, l3 = cond_ode_likelihood(net, cvec.repeat_interleave(K, 0).contiguous(), 1, x, probe, rtol=1e-4, atol=1e-4, stats=s3)
+    assert z1.dtype == torch.float64 and l1.shape == (B * K,) and torch.isfinite(l1).all()
+    assert torch.equal(l1, l2) and torch.equal(z1, z2) and s1 == s2
+    assert s1["nfev"] == s3["nfev"] and s1["nfev"] == 2 + 6 * s1["attempts"]
+    np.testing.assert_allclose(l1.cpu().numpy(), l3.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(l1.abs().max()))
+    with pytest.raises(RuntimeError):
+        solver.run(cvec, torch.zeros(B, 3, device="cuda"), x, 0.5)  # a likelihood solver does not sample
