@@ -53,7 +53,7 @@ SIGNATURES = {
     "gp_energy_score": [c_int, c_int, NETP, P, P, P, P, P, P, P],
     "gp_pc_tile_rows": [c_int, c_int, c_int],
     "gp_pc_layout": [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
-    "gp_pc_step_plan": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 12 + [P],
+    "gp_pc_step_plan": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 12 + [c_int, P],
     "gp_score_eval_plan": [c_int, c_int, c_int, NETP, P, P, P, P, c_int, P, P],
     "gp_pc_step_grouped": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
     "gp_pc_step_coupled": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 12 + [P],
@@ -62,7 +62,8 @@ SIGNATURES = {
     "gp_rk45_set_dense": [P, P, c_int, P, P],
     "gp_rk45_phase": [c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
     "gp_rk45_phase_grouped": [c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
-    "gp_rk45_phase_model": [c_int, P, c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
+    "gp_rk45_phase_model": [c_int, P, c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5
+                           + [c_int, c_int, P, P, c_int, P],
     "gp_rk45_set_dense_grouped": [c_int, P, P, c_int, P, P],
     "gp_rk45_phase_ragged": [c_int, c_int, P, c_int, P, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5
                             + [c_int, c_int, P, P],

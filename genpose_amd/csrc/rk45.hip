@@ -79,6 +79,11 @@ struct OdeArgs {
     float *x32;                // [R*9] scratch
     const float *probe;        // [R][9] Hutchinson probe of the likelihood ODE (model 2) or null
     int ncomp;                 // state components per row: 9 (pose), 10 for the likelihood ODE (pose + log-density change)
+    // a batch sharded over several GPUs: the norms of the step controller run over ALL its rows.  ext_sums [2][ngroups]: this rank's
+    // per-group sums of squares (rk45_group_sums_kernel), all-reduced by the caller between the stage kernels and the controller;
+    // ext_rows = rows of a group over all ranks.  null: the controller reduces the local partials itself.
+    double *ext_sums;
+    int ext_rows;
 };
 
 // MODEL of the right-hand side (the same Dormand-Prince driver integrates all three):
@@ -262,10 +267,11 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
         if (threadIdx.x == 0) st->status = 1;
         return;
     }
-    const double nn = (double)grows * (double)a.ncomp;  // size of the state vector the RMS norms run over
+    const double nn = (double)(a.ext_sums ? a.ext_rows : grows) * (double)a.ncomp;  // size of the state vector the RMS norms run over
+    const int ng = gridDim.x;
     if (mode == 0) {
-        const double s0 = sum_partials(part, nblk, sh);
-        const double s1 = sum_partials(part + a.nblocks, nblk, sh);
+        const double s0 = a.ext_sums ? a.ext_sums[blockIdx.x] : sum_partials(part, nblk, sh);
+        const double s1 = a.ext_sums ? a.ext_sums[ng + blockIdx.x] : sum_partials(part + a.nblocks, nblk, sh);
         if (threadIdx.x == 0) {
             const double d0 = sqrt(s0) / sqrt(nn), d1 = sqrt(s1) / sqrt(nn);  // norm(x) = |x|_2 / sqrt(size)
             const double interval = fabs(st->t_bound - st->t);
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
             st->nfev = 1;
         }
     } else if (mode == 1) {
-        const double s0 = sum_partials(part, nblk, sh);
+        const double s0 = a.ext_sums ? a.ext_sums[blockIdx.x] : sum_partials(part, nblk, sh);
         if (threadIdx.x == 0) {
             const double d2 = (sqrt(s0) / sqrt(nn)) / st->h0;
             const double d1 = st->d1;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
         }
     } else {
         if (st->status != 0) return;
-        const double s0 = sum_partials(part, nblk, sh);
+        const double s0 = a.ext_sums ? a.ext_sums[blockIdx.x] : sum_partials(part, nblk, sh);
         if (threadIdx.x == 0) {
             const double err = sqrt(s0) / sqrt(nn);
             const int ia = st->n_attempts;
@@ -334,6 +340,17 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
             st->h_abs = h_abs;
             if (st->status == 0) begin_attempt(st);
         }
+    }
+}
+
+// Sharded batch: this rank's per-group sums of the stage kernels' partials (fixed order) -> ext_sums, for the caller's all-reduce.
+__global__ __launch_bounds__(256) void rk45_group_sums_kernel(OdeArgs a, int nsums) {
+    __shared__ double sh[8];
+    const int blk0 = a.grp_info ? a.grp_info[4 * blockIdx.x] : blockIdx.x * a.bpg;
+    const int nblk = a.grp_info ? a.grp_info[4 * blockIdx.x + 1] : a.bpg;
+    for (int w = 0; w < nsums; ++w) {
+        const double s = sum_partials(a.partials + (size_t)w * a.nblocks + blk0, nblk, sh);
+        if (threadIdx.x == 0) a.ext_sums[(size_t)w * gridDim.x + blockIdx.x] = s;
     }
 }
 
@@ -519,12 +536,28 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             hipLaunchKernelGGL(rk45_reset_kernel, dim3(a.ngroups), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
             if (traj && hipMemcpyAsync(traj, y, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return GP_ELAUNCH;
             break;
+        // with ext_sums (a batch sharded over several GPUs) phases 1-3 stop after the per-group sums and phases 11-13 run the
+        // controller on the all-reduced sums
         case 1:
             hipLaunchKernelGGL((rk45_stage_kernel<P, 0, MODEL>), grid, blk, lds, st, a, *net);
+            if (a.ext_sums)
+                hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
+            else
+                hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 0);
+            break;
+        case 11:
+            if (!a.ext_sums) return GP_EINVAL;
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 0);
             break;
         case 2:
             hipLaunchKernelGGL((rk45_stage_kernel<P, 7, MODEL>), grid, blk, lds, st, a, *net);
+            if (a.ext_sums)
+                hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
+            else
+                hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
+            break;
+        case 12:
+            if (!a.ext_sums) return GP_EINVAL;
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
             break;
         case 3:
@@ -534,6 +567,15 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             hipLaunchKernelGGL((rk45_stage_kernel<P, 4, MODEL>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL((rk45_stage_kernel<P, 5, MODEL>), grid, blk, lds, st, a, *net);
             hipLaunchKernelGGL((rk45_stage_kernel<P, 6, MODEL>), grid, blk, lds, st, a, *net);
+            if (a.ext_sums) {
+                hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
+                break;
+            }
+            hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
+            if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64, a.ngroups), blk1, 0, st, a);
+            break;
+        case 13:
+            if (!a.ext_sums) return GP_EINVAL;
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
             if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64, a.ngroups), blk1, 0, st, a);
             break;
@@ -610,6 +652,7 @@ static int ode_args(OdeArgs *a, int *tile, int model, const float *probe, int ng
     a->cvec = cvec, a->tvec = tvec, a->centre = centre, a->st = (Rk45State *)state;
     a->y = y, a->ynew = ynew, a->K = K, a->partials = partials, a->traj = traj, a->x32 = x32;
     a->probe = probe, a->ncomp = model == 2 ? 10 : 9;
+    a->ext_sums = nullptr, a->ext_rows = 0;
     *tile = P;
     return GP_OK;
 }
@@ -630,11 +673,13 @@ static int ode_args(OdeArgs *a, int *tile, int model, const float *probe, int ng
 int gp_rk45_phase_model(int model, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         const float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
-                        double *x_out, gp_stream_t s) {
+                        double *x_out, double *ext_sums, int ext_rows_per_group, gp_stream_t s) {
     OdeArgs a;
     int P = 0;
     int rc = ode_args(&a, &P, model, probe, ngroups, nclouds_per_group, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
     if (rc != GP_OK || !net) return GP_EINVAL;
+    if (ext_sums && ext_rows_per_group < a.rows_per_group) return GP_EINVAL;
+    a.ext_sums = ext_sums, a.ext_rows = ext_rows_per_group;
     if (model != 0 && (!net->w_headx_t || !net->w_pose2_t || !net->w_pose0_t)) return GP_EINVAL;
 #define GP_RK45_CALL(PP, MM) \
     rk45_phase_impl<PP, MM>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out, (hipStream_t)s)
@@ -649,7 +694,7 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
                           double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                           gp_stream_t s) {
     return gp_rk45_phase_model(0, nullptr, phase, ngroups, nclouds_per_group, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap, t0,
-                               t_bound, rtol, atol, denoise_scale, do_denoise, nstates, x_out, s);
+                               t_bound, rtol, atol, denoise_scale, do_denoise, nstates, x_out, nullptr, 0, s);
 }
 
 int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nblocks, const int32_t *blk_info, int tile, int nclouds_total, int k,
@@ -666,6 +711,7 @@ int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nb
     a.cvec = cvec, a.tvec = tvec, a.centre = centre, a.st = (Rk45State *)state;
     a.y = y, a.ynew = ynew, a.K = K, a.partials = partials, a.traj = traj, a.x32 = nullptr;
     a.probe = nullptr, a.ncomp = 9;
+    a.ext_sums = nullptr, a.ext_rows = 0;
     return tile == 16 ? rk45_phase_impl<16, 0>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
                                                (hipStream_t)s)
                       : rk45_phase_impl<32, 0>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,

@@ -168,8 +168,9 @@ struct PcArgs {
     const float *z_lang, *z_pred;    // [nsteps][R][9]
     const float *centre;             // [R/k... per cloud][3]
     float *x, *mean_x, *score, *partials, *traj;  // x,mean_x,score [R,9]; partials [nsteps][nparts]; traj [nsteps][R][9] or null
-    const float *gn_ext;             // [nsteps][ngroups] or null: the batch-mean gradient norm supplied from outside (a batch that is
-    int ngroups;                     //   sharded over several GPUs: the mean over ALL its rows, all-reduced between the launches)
+    const float *gn_ext;             // [nsteps][ngroups] or null: the batch's gradient-norm statistic supplied from outside (a batch that is
+    int ngroups;                     //   sharded over several GPUs, all-reduced between the launches): the SUM of |score| over all its
+    float gn_rows;                   //   rows when gn_rows > 0 (= that row count), else the mean itself
 };
 
 // Kernel for step i (0 <= i <= nsteps):
@@ -217,7 +218,10 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         }
         constexpr int LASTW = TrunkCfg<P>::NT - 64;
         if (a.gn_ext) {
-            if (tid == LASTW) s_gn = a.gn_ext[(size_t)(i - 1) * a.ngroups + blockIdx.x / a.wgpg];
+            if (tid == LASTW) {
+                const float v = a.gn_ext[(size_t)(i - 1) * a.ngroups + blockIdx.x / a.wgpg];
+                s_gn = a.gn_rows > 0.f ? v / a.gn_rows : v;
+            }
         } else if (tid >= LASTW) {
             float s = 0.f;
             const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)(blockIdx.x / a.wgpg) * a.ppg;
@@ -336,6 +340,7 @@ __global__ __launch_bounds__(gp_chain::NT, 1) void pc_step_chain_kernel(PcArgs a
         const int grp = blockIdx.x / a.wgpg;
         if (a.gn_ext) {
             gn = a.gn_ext[(size_t)(i - 1) * a.ngroups + grp];
+            if (a.gn_rows > 0.f) gn = gn / a.gn_rows;
         } else {
             float s = 0.f;
             const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)grp * a.ppg;
@@ -525,9 +530,9 @@ int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k,
 
 int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                     const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x,
-                    float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
+                    float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, int gn_rows_total, gp_stream_t s) {
     if (ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || step < 0 || step > nsteps || !net || !cvec || !tvec_all || !sched || !z_langevin ||
-        !z_predictor || !centre || !x || !mean_x || !score || !partials)
+        !z_predictor || !centre || !x || !mean_x || !score || !partials || gn_rows_total < 0)
         return GP_EINVAL;
     const int rg = nclouds_per_group * k, R = ngroups * rg;
     if (R == 0) return GP_OK;
@@ -541,7 +546,7 @@ int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int
     a.wgpg = (rg + pc_rows_per_wg(P) - 1) / pc_rows_per_wg(P);
     a.cvec = cvec, a.tvec_all = tvec_all, a.sched = sched, a.z_lang = z_langevin, a.z_pred = z_predictor, a.centre = centre;
     a.x = x, a.mean_x = mean_x, a.score = score, a.partials = partials, a.traj = traj;
-    a.gn_ext = gn_ext, a.ngroups = ngroups;
+    a.gn_ext = gn_ext, a.ngroups = ngroups, a.gn_rows = (float)gn_rows_total;
     hipStream_t st = (hipStream_t)s;
     const int nwg = a.wgpg * ngroups;
     if (P == 128) return launch_pc_chain<2>(a, net, nwg, st);
@@ -565,21 +570,21 @@ int gp_pc_step_coupled(int ngroups, int nclouds_per_group, int k, int step, int 
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
                        float *x, float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
     return gp_pc_step_plan(0, 0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
-                           partials, traj, gn_ext, s);
+                           partials, traj, gn_ext, 0, s);
 }
 
 int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
                        float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s) {
     return gp_pc_step_plan(0, 0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
-                           partials, traj, nullptr, s);
+                           partials, traj, nullptr, 0, s);
 }
 
 int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec, const float *tvec_all,
                const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
                float *score, float *partials, float *traj, gp_stream_t s) {
     return gp_pc_step_plan(0, 0, 1, nclouds, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score, partials, traj,
-                           nullptr, s);
+                           nullptr, 0, s);
 }
 
 }  // extern "C"

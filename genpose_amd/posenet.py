@@ -137,10 +137,11 @@ class GFObjectPose:
             T0 = self.T if T0 is None else T0
             pr = self._prior_to_device((R, 9), T=T0)
             x0 = pr if init_x is None else init_x.float() + pr
-            key = ("ode", B, K)
+            coupling = getattr(self, "coupling_group", None)  # batch sharded over the ranks of that group: error norm over ALL its rows
+            key = ("ode", B, K, id(coupling) if coupling is not None else None)
             smp = self._samplers.get(key)
             if smp is None:
-                smp = self._samplers[key] = ODESampler(self.pose_score_net, B, K, self.device)
+                smp = self._samplers[key] = ODESampler(self.pose_score_net, B, K, self.device, coupling_group=coupling)
             return smp.run(cvec, centre, x0, T0, num_steps=self.cfg.sampling_steps, eps=self.sampling_eps, return_process=return_process)
         raise NotImplementedError(sampler)
 

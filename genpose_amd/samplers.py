@@ -32,8 +32,9 @@ class PCSampler:
         coupling_group (a torch.distributed process group; "faithful" multi-GPU mode, SURVEY §8e caveat): this rank's B clouds are
         one SHARD of a batch that is spread over the ranks of the group (equal shards).  After every step the per-batch sums of
         |score| are all-reduced (one float per batch) and the next launch takes the mean over ALL rows of the batch
-        (gp_pc_step_coupled), so every shard steps exactly as the unsharded batch would.  The loop then runs launch by launch (an
-        all-reduce sits between consecutive launches), not as one captured graph."""
+        (gp_pc_step_plan with gn_ext), so every shard steps exactly as the unsharded batch would.  On RCCL (backend 'nccl') the
+        per-step reduction - one device-side sum and one all-reduce of `groups` floats - is captured INSIDE the sampler's hipGraph
+        with the launches; on gloo (CPU tests, two ranks sharing one device) the loop runs launch by launch."""
         if B % groups:
             raise ValueError(f"{B} clouds do not split into {groups} equal batches")
         if model not in ("score", "energy"):
@@ -65,13 +66,14 @@ class PCSampler:
         self.cvec, self.centre = f(B, 768), f(B, 3)
         self.traj = f(num_steps, R, 9) if record_traj else None
         self.coupling_group = coupling_group
-        self.gn_ext = None
+        self.gn_ext, self.gn_rows = None, 0
         if coupling_group is not None:
             import torch.distributed as dist
             self._dist = dist
             self._world = dist.get_world_size(coupling_group)
             self.gn_ext = torch.zeros(num_steps, groups, device=self.dev)
-            use_graph = False
+            self.gn_rows = R // groups * self._world  # rows of a batch over all its (equal) shards
+            use_graph = use_graph and dist.get_backend(coupling_group) == "nccl"  # an RCCL all-reduce is graph-capturable, a gloo one is not
         self.use_graph = use_graph
         self.graph = None
 
@@ -79,16 +81,15 @@ class PCSampler:
         """Launch i of the chain (0 <= i <= n) on the current stream: finishes step i-1 and, for i < n, evaluates the score at t_i."""
         _lib.call("gp_pc_step_plan", self.model, self.tile, self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
                   ptr(self.sched), ptr(self.z1), ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
-                  ptr(self.traj), ptr(self.gn_ext), stream_ptr())
+                  ptr(self.traj), ptr(self.gn_ext), self.gn_rows, stream_ptr())
 
     def _launch_all(self):
         for i in range(self.n + 1):
             self.launch_step(i)
             if self.coupling_group is not None and i < self.n:
-                # sum of |score_i| over this shard's rows, per batch -> over all shards -> mean over all rows of the batch
-                tot = self.partials[i].view(self.groups, -1).sum(dim=1)
-                self._dist.all_reduce(tot, op=self._dist.ReduceOp.SUM, group=self.coupling_group)
-                self.gn_ext[i].copy_(tot / float(self.R // self.groups * self._world))
+                # sum of |score_i| over this shard's rows, per batch -> over all shards (the kernel divides by the batch's row count)
+                torch.sum(self.partials[i].view(self.groups, -1), dim=1, out=self.gn_ext[i])
+                self._dist.all_reduce(self.gn_ext[i], op=self._dist.ReduceOp.SUM, group=self.coupling_group)
 
     def run(self, cvec, centre, init_x, z_langevin=None, z_predictor=None, slot_free_event=None, graph_events=None):
         """cvec [B,768], centre [B,3], init_x [R,9]; noise [n,R,9] (drawn on the device generator if None).
@@ -150,14 +151,20 @@ class ODESampler:
 
     MODELS = {"score": 0, "energy": 1, "likelihood": 2}
 
-    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None, model="score"):
+    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None, model="score", coupling_group=None):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: every batch keeps its own adaptive
         step control (error norm over ITS rows, accept / reject, step size - what separate cond_ode_sampler calls would do) while
         all of them share each launch (gp_rk45_phase_grouped).
 
         model: what the driver integrates (gp_rk45_phase_model) - 'score' the probability-flow ODE of the score network; 'energy' the
         same ODE with the ENERGY network's score (`net` holds its weights; forward + vector-Jacobian product inside the stage
-        kernels); 'likelihood' the [pose, log-density] ODE of cond_ode_likelihood (run_likelihood)."""
+        kernels); 'likelihood' the [pose, log-density] ODE of cond_ode_likelihood (run_likelihood).
+
+        coupling_group (a torch.distributed process group; "faithful" multi-GPU mode, SURVEY §8e caveat): this rank's B clouds are one
+        SHARD of a batch spread over the ranks of the group (equal shards).  scipy's error norm - and the norms of its initial-step
+        heuristic - run over the WHOLE batch: after the stage kernels the per-group sums of squares are all-reduced (two doubles per
+        group) and the step controller decides on the reduced sums, so every shard takes the accept / reject sequence of the unsharded
+        batch.  On RCCL the all-reduce is captured with the attempts; on gloo the attempts run launch by launch."""
         self.model = self.MODELS[model]
         self.ncomp = 10 if self.model == 2 else 9
         self.ragged = group_clouds is not None
@@ -194,6 +201,15 @@ class ODESampler:
         self.partials = d(3, self.nblocks)
         self.x_out = d(R, nc)
         self.probe = torch.zeros(R, 9, device=self.dev) if self.model == 2 else None
+        self.coupling_group, self.ext_sums, self.ext_rows = coupling_group, None, 0
+        if coupling_group is not None:
+            if self.ragged:
+                raise NotImplementedError("ragged groups are not sharded")
+            import torch.distributed as dist
+            self._dist = dist
+            self.ext_sums = d(2, groups)
+            self.ext_rows = R // groups * dist.get_world_size(coupling_group)
+            use_graph = use_graph and dist.get_backend(coupling_group) == "nccl"
         self.tvec = torch.zeros(groups * 8, 768, device=self.dev)
         self.cvec = torch.empty(B, 768, device=self.dev)
         self.centre = torch.empty(B, 3, device=self.dev)
@@ -247,7 +263,13 @@ class ODESampler:
             _lib.call("gp_rk45_phase_ragged", phase, self.groups, ptr(self.grp_info), self.nblocks, ptr(self.blk_info), self.tile, self.B, self.K,
                       self.net.w.ref(), *tail)
         else:
-            _lib.call("gp_rk45_phase_model", self.model, ptr(self.probe), phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail)
+            _lib.call("gp_rk45_phase_model", self.model, ptr(self.probe), phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail[:-1],
+                      ptr(self.ext_sums), self.ext_rows, tail[-1])
+            if self.ext_sums is not None and phase in (1, 2, 3):
+                # sharded batch: the controller decides on the sums of squares over ALL shards
+                self._dist.all_reduce(self.ext_sums, op=self._dist.ReduceOp.SUM, group=self.coupling_group)
+                _lib.call("gp_rk45_phase_model", self.model, ptr(self.probe), phase + 10, self.groups, self.B // self.groups, self.K, self.net.w.ref(),
+                          *tail[:-1], ptr(self.ext_sums), self.ext_rows, tail[-1])
 
     def _embed(self):
         import ctypes

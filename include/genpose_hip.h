@@ -226,10 +226,13 @@ int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k,
  * plan) and the MODEL whose score drives the sampler: 0 = the score network (f / (sigma + 1e-7), scorenet.py:217); 1 = the ENERGY
  * network (`net` = its parameter block): the reference samples from it with the autograd gradient of its inner-product energy
  * (posenet.py:94-130 with PoseEnergyNet.forward(return_item='score'), energynet.py:200-222) - here the forward pass and the
- * vector-Jacobian product run inside the step kernel (16-row tiles), so the energy model gets the same one-graph launch chain. */
+ * vector-Jacobian product run inside the step kernel (16-row tiles), so the energy model gets the same one-graph launch chain.
+ * gn_ext / gn_rows_total: as gp_pc_step_coupled when gn_rows_total = 0 (gn_ext = the mean); with gn_rows_total > 0, gn_ext [nsteps][ngroups]
+ * holds the SUM of |score| over all rows of the batch (this rank's per-group sum of `partials`, all-reduced in place) and
+ * gn_rows_total that row count: one device-side sum and one all-reduce per step, both capturable in the sampler's hipGraph. */
 int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                     const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x,
-                    float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s);
+                    float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, int gn_rows_total, gp_stream_t s);
 
 /* The same launch with the batch-mean gradient norm SUPPLIED: gn_ext [nsteps][ngroups] (device) holds, for step i, the mean of
  * |score_i| over ALL rows of the batch each group belongs to.  For a batch that is sharded over several GPUs (SURVEY §8e caveat): the
@@ -283,11 +286,16 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
  *      d logp / dt = -g^2/2 probe^T (d score / d x) probe with the fixed Skilling-Hutchinson `probe` [R][9] (device); y, ynew [R*10],
  *      K [7][R*10]; one error norm over all R*10 components (scipy integrates the concatenated vector); phase 5 copies the final
  *      state to x_out [R][10] (no denoise / normalisation); phases 4 and the trajectory arguments are unused.
- * Models 1 and 2 run on 16-row tiles: partials [3][ngroups * ceil(rows_per_group / 16)]. */
+ * Models 1 and 2 run on 16-row tiles: partials [3][ngroups * ceil(rows_per_group / 16)].
+ * A batch SHARDED over several GPUs (SURVEY §8e caveat: scipy's error norm runs over the whole batch): ext_sums [2][ngroups] (device,
+ * f64) and ext_rows_per_group = rows of a group over all ranks.  Phases 1, 2, 3 then stop after writing this rank's per-group sums of
+ * squares to ext_sums; the caller all-reduces ext_sums (RCCL: capturable with the launches) and runs phase 11, 12 or 13 = the step
+ * controller on the reduced sums (+ trajectory record).  Every shard then takes the accept / reject sequence of the unsharded batch.
+ * ext_sums = NULL: the controller reduces the local partials itself (phases 11-13 are GP_EINVAL). */
 int gp_rk45_phase_model(int model, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         const float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
-                        double *x_out, gp_stream_t s);
+                        double *x_out, double *ext_sums, int ext_rows_per_group, gp_stream_t s);
 /* Ragged variant: groups with different numbers of clouds (tracking: the objects of one frame form a group, frames of different
  * sequences share the launches).  grp_info [ngroups][4] = {first workgroup, workgroups, rows, first row}; blk_info [nblocks][3] =
  * {group, first row, end row (exclusive) of the group} per workgroup of `tile` (16 or 32) rows; both device int32.  Rows stay
