@@ -82,6 +82,11 @@ def parse():
     ap.add_argument("--cpu-clouds", type=int, default=64, help="clouds of the CPU-baseline sample (BASELINE.md §3: one 64-cloud batch)")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work the baseline leg may spend")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / ODE-100 side measurements")
+    ap.add_argument("--tracking", action="store_true",
+                    help="BASELINE configs[4]: tracking mode - every rank streams --sequences whole sequences (warm-started candidates, PF-ODE "
+                         "sampler from T0 = 0.15, energy ranking, aggregation per frame); a step = one frame of every sequence")
+    ap.add_argument("--sequences", type=int, default=64, help="tracking: concurrent sequences per GPU")
+    ap.add_argument("--objects", type=int, default=5, help="tracking: objects per frame")
     return ap.parse_args()
 
 
@@ -135,6 +140,11 @@ def main():
     from genpose_amd.posenet_agent import PoseNet
     from genpose_amd.weights_synth import make_state_dict
 
+    if args.tracking:
+        tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     B, K, n = args.batch, args.cand, args.sde_steps
     steps = n if args.sampler == "pc" else None
     score_agent = PoseNet(get_config(device=str(dev), posenet_mode="score", sampler_mode=[args.sampler], sampling_steps=steps))
@@ -252,7 +262,7 @@ def main():
     roofline = None
     nfev = n
     if args.sampler == "pc" and full_pred is None:
-        smp = pipe._sampler(0, G) if pipe is not None else score_agent.net._samplers[("pc", B, K, n, False)]
+        smp = pipe._sampler(0, G) if pipe is not None else score_agent.net.last_sampler
         roofline = pc_roofline(torch, smp, G * B * K, n)
         in_situ = pipe.sampler_launch_seconds() if pipe is not None else None
         if in_situ:
@@ -261,7 +271,7 @@ def main():
         if ode_grouped:
             nfev = int(round(sum(ode_pred.last_nfev) / max(1, len(ode_pred.last_nfev))))
         else:
-            nfev = int(score_agent.net._samplers[("ode", B, K)].last_stats["nfev"])
+            nfev = int(score_agent.net.last_sampler.last_stats["nfev"])
 
     side = {}
     if rank == 0 and world == 1:
@@ -306,6 +316,95 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend):
+    """BASELINE configs[4] (evaluation_tracking.py path): the path does not shard below a sequence (frames are sequential: warm start),
+    so every rank owns WHOLE sequences (dist.ShardedTracking: replicas only, no data-path collective) and drives them in lock-step
+    through one MultiSequenceTracker - the frames its sequences are at share every launch (one encoder pass, one device-resident RK45
+    solve with a step controller per sequence, one energy pass, one ranking launch).  A step = one frame of every sequence of the
+    rank; value = poses (objects x frames) per second over all ranks; the per-frame results are gathered once per timed block."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.dist import ShardedTracking
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.runner import MultiSequenceTracker
+    from genpose_amd.weights_synth import make_state_dict
+    S, n_obj, K, T0, nfr = args.sequences, args.objects, args.cand, 0.15, 30
+    sa = PoseNet(get_config(device=str(dev), posenet_mode="score", sampler_mode=["ode"]))
+    sa.load_state_dict(make_state_dict(0, "score"))
+    ea = PoseNet(get_config(device=str(dev), posenet_mode="energy"))
+    ea.load_state_dict(make_state_dict(0, "energy"))
+    st = ShardedTracking(lambda nloc: MultiSequenceTracker(sa, ea, nloc, repeat_num=K, T0=T0, max_objects_per_frame=max(8, n_obj)), world * S)
+    seqs = []
+    for sq in st.owned():  # REAL275-shaped synthetic sequences: n_obj objects drifting 2 mm per frame, 30 frames, then the sequence restarts
+        base = torch.from_numpy(synth.make_batch(n_obj, start=50 * sq))
+        gt = torch.eye(4).repeat(n_obj, 1, 1)
+        gt[:, :3, 3] = base.mean(dim=1)
+        seqs.append(([(base + 0.002 * f).to(dev) for f in range(nfr)], [f"s{sq}o{j}" for j in range(n_obj)], gt))
+    clock = [0]
+
+    def frame_step():
+        f = clock[0] % nfr
+        if f == 0:
+            st.tracker.reset()  # a new 30-frame sequence: no warm start across the boundary
+        out = st.tracker.step([(q[0][f], q[1], q[2]) for q in seqs])
+        clock[0] += 1
+        return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def gather(out):
+        if dist is not None:  # the path's only exchange: the per-frame results of every sequence
+            o = torch.stack([r["average_sRT"] for r in out]).contiguous()
+            o = o.cpu() if one_dev else o
+            dist.all_gather([torch.empty_like(o) for _ in range(world)], o)
+
+    for _ in range(max(2, args.warmup)):
+        out = frame_step()
+    barrier()
+
+    def timed_block():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = frame_step()
+        gather(out)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], device="cpu" if one_dev else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, [int(r["nfev"]) for r in out]
+
+    blocks = [timed_block()]
+    reps = args.repeats if args.repeats > 0 else max(1, min(16, math.ceil(1.0 / blocks[0][0])))
+    while len(blocks) < reps:
+        blocks.append(timed_block())
+    times = sorted(b[0] for b in blocks)
+    elapsed = statistics.median(times)
+    nfev = statistics.median(blocks[-1][1])
+    if rank == 0:
+        value = world * S * n_obj * args.steps / elapsed
+        flop_per_pose = 2 * (FLOP_ENCODER + FLOP_CLOUD_EMBED) + K * (nfev + 1) * FLOP_SCORE_ROW
+        print(json.dumps({
+            "metric": "poses/sec (1024-pt cloud, 50 cand, tracking: warm-started PF-ODE)", "value": round(value, 2), "unit": "poses/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[4]: tracking, {S} sequences/GPU x 30 frames, {n_obj} objects/frame x 1024 pts, {K} candidates, "
+                                   f"PF-ODE RK45 from T0={T0} (NFE={nfev}) + EnergyNet ranking + top-60% aggregation per frame",
+                       "sequences_per_gpu": S, "objects_per_frame": n_obj, "candidates": K, "sampler": "ode", "T0": T0, "nfev": nfev,
+                       "frames_per_s": round(world * S * args.steps / elapsed, 1), "weights": "seeded random (reference state-dict schema)",
+                       "parallelism": f"whole sequences per rank x{world} (replicas only)"},
+            "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": round(sum(times), 3), "block_ms_median": round(elapsed * 1e3, 3),
+                       "block_ms_min": round(times[0] * 1e3, 3), "block_ms_max": round(times[-1] * 1e3, 3), "statistic": "median block"},
+            "launch": {"mode": os.environ.get("GP_BENCH_LAUNCH", "direct" if world == 1 else "torch.distributed.run"),
+                       "world_size_observed": (dist.get_world_size() if dist is not None else 1), "backend": backend},
+            "whole_path_tflops": round(value * flop_per_pose / 1e12, 2), "roofline": None, "cpu_baseline": None}), flush=True)
 
 
 def pc_roofline(torch, smp, rows, n):

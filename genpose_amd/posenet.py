@@ -131,6 +131,7 @@ class GFObjectPose:
                 smp = self._samplers[key] = PCSampler(self.pose_score_net, B, K, n, self.device, record_traj=return_process,
                                                       coupling_group=coupling)
             z1, z2 = noise if noise is not None else (None, None)
+            self.last_sampler = smp  # statistics / timing of the sampler that served the last call
             xs, res = smp.run(cvec, centre, x0, z1, z2)
             return (xs.clone() if xs is not None else None), res.clone()
         if sampler == "ode":
@@ -142,6 +143,7 @@ class GFObjectPose:
             smp = self._samplers.get(key)
             if smp is None:
                 smp = self._samplers[key] = ODESampler(self.pose_score_net, B, K, self.device, coupling_group=coupling)
+            self.last_sampler = smp
             return smp.run(cvec, centre, x0, T0, num_steps=self.cfg.sampling_steps, eps=self.sampling_eps, return_process=return_process)
         raise NotImplementedError(sampler)
 

@@ -8,7 +8,7 @@ B, K, n = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 50, 100
 sa = PoseNet(get_config(posenet_mode="score", sampler_mode=["pc"], sampling_steps=n)); sa.load_state_dict(make_state_dict(0, "score"))
 pts = torch.from_numpy(synth.make_batch(B)).cuda(); cen = pts.mean(1)
 sa.pred_func({"pts": pts, "pts_center": cen}, repeat_num=K, save_path=None); torch.cuda.synchronize()
-smp = sa.net._samplers[("pc", B, K, n, False)]
+smp = sa.net.last_sampler
 feat = sa.net.pts_encoder(pts); cvec = sa.net.pose_score_net.cloud_embed(feat); x0 = torch.randn(B * K, 9, device="cuda")
 def series(name, fn, reps=12):
     ts = []

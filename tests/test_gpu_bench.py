@@ -47,3 +47,27 @@ def test_one_rank_direct_and_through_the_launcher_agree():
         assert direct[k] == spawned[k], k
     assert direct["roofline"]["kernel"] == spawned["roofline"]["kernel"]
     assert direct["roofline"]["flops_per_launch"] == spawned["roofline"]["flops_per_launch"]
+
+
+def test_config3_full_pipeline_two_ranks_on_one_device():
+    """BASELINE configs[3] shape (--pipeline full, clouds sharded, one gather of the aggregated poses per batch) through the N-rank path."""
+    line = _run(["--gpus", "2", "--pipeline", "full"], {"GP_BENCH_ONE_DEVICE": "1"})
+    assert REQUIRED <= set(line) and line["n_gpus"] == 2 and line["launch"]["world_size_observed"] == 2
+    assert line["config"]["pipeline"] == "full" and "EnergyNet ranking" in line["config"]["workload"] and line["value"] > 0
+
+
+def test_config4_tracking_two_ranks_on_one_device():
+    """BASELINE configs[4]: --tracking (whole sequences per rank, MultiSequenceTracker per rank, results gathered per block)."""
+    env = {"GP_BENCH_ONE_DEVICE": "1"}
+    extra = ["--gpus", "2", "--tracking", "--sequences", "3", "--objects", "2", "--cand", "10", "--steps", "3", "--warmup", "2", "--repeats", "1"]
+    envd = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        envd.pop(k, None)
+    envd.update(env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=envd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert REQUIRED <= set(line) and line["n_gpus"] == 2 and line["config"]["sequences_per_gpu"] == 3 and line["config"]["sampler"] == "ode"
+    assert line["value"] > 0 and abs(line["value"] - 2 * 3 * 2 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"]

@@ -179,7 +179,7 @@ def test_multi_sequence_tracker_equals_per_sequence_runs():
         for f in range(n_frames):
             sa.net.prior_fn = lambda shape, T=1.0, f=f, s_=s_: priors[f][s_]
             r = tr.step(seqs[s_]["pts"][f], seqs[s_]["names"], seqs[s_]["gt"], noise_draws=draws[f][s_])
-            r["nfev"] = int(sa.net._samplers[("ode", c, K)].last_stats["nfev"])
+            r["nfev"] = int(sa.net.last_sampler.last_stats["nfev"])
             res.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()})
         ref.append(res)
     multi = MultiSequenceTracker(sa, ea, len(counts), repeat_num=K, T0=T0)
@@ -238,8 +238,44 @@ def test_multi_sequence_tracker_changing_object_counts():
         for s_, c in enumerate(counts):
             sa.net.prior_fn = lambda shape, T=1.0, s_=s_: priors[s_]
             r = singles[s_].step(frames[s_][0], frames[s_][1], frames[s_][2], noise_draws=draws[s_])
-            nfev = int(sa.net._samplers[("ode", c, K)].last_stats["nfev"])
+            nfev = int(sa.net.last_sampler.last_stats["nfev"])
             assert got[s_]["nfev"] == nfev, (f, s_, got[s_]["nfev"], nfev)
             scale = max(1.0, float(r["pred_pose"].abs().max()))
             np.testing.assert_allclose(got[s_]["pred_pose"].cpu().numpy(), r["pred_pose"].cpu().numpy(), rtol=0, atol=5e-4 * scale)
             np.testing.assert_allclose(got[s_]["average_sRT"].cpu().numpy(), r["average_sRT"].cpu().numpy(), rtol=0, atol=2e-3)
+
+
+def test_tracking_frame_graphs_equal_the_agent_calls():
+    """TrackingRunner(use_graphs=True) replays two hipGraphs per frame around the adaptive solve (clouds -> both models' embeddings;
+    candidates -> energies -> ranking -> aggregate); the results are the agents' pred_func -> get_energy -> rank_aggregate, bit for
+    bit, over several frames incl. a change of the object count."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.runner import TrackingRunner
+    sa = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"]))
+    sa.load_state_dict(go.make_state_dict(0, "score"))
+    ea = PoseNet(get_config(posenet_mode="energy"))
+    ea.load_state_dict(go.make_state_dict(0, "energy"))
+    K = 10
+    gen = torch.Generator().manual_seed(77)
+    frames = []
+    for f, n in enumerate((3, 3, 4, 3)):
+        base = torch.from_numpy(synth.make_batch(n, start=1200)) + 0.002 * f
+        gt = torch.eye(4).repeat(n, 1, 1)
+        gt[:, :3, 3] = base.mean(dim=1)
+        draws = [torch.randn(n, generator=gen), torch.randn(n, 4, generator=gen), torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen)]
+        frames.append((base.cuda(), [f"o{j}" for j in range(n)], gt, draws, torch.randn(n * K, 9, generator=gen) * 0.04))
+    outs = {}
+    for graphs in (True, False):
+        tr = TrackingRunner(sa, ea, repeat_num=K, T0=0.15, use_graphs=graphs)
+        res = []
+        for pts, names, gt, draws, prior in frames:
+            sa.net.prior_fn = lambda shape, T=1.0, p=prior: p.clone()
+            res.append({k: v.clone() for k, v in tr.step(pts, names, gt, noise_draws=draws).items()})
+        outs[graphs] = res
+        torch.cuda.synchronize()
+    assert tr._graphs is None and len(outs[True]) == 4
+    for a, b in zip(outs[True], outs[False]):
+        for k in ("init_x", "pred_pose", "energy", "sorted_RTs", "average_sRT"):
+            assert torch.equal(a[k], b[k]), k

@@ -62,7 +62,7 @@ def test_ode_golden(golden, case):
     pred, proc = out
     assert pred.dtype == torch.float64 and "pts_feat" in data
     ode_close(pred.cpu().numpy(), g[f"{case}_pred"])
-    stats = agent.net._samplers[("ode", 2, 10)].last_stats
+    stats = agent.net.last_sampler.last_stats
     ref_nfev = len(g[f"{case}_eval_t"])
     assert stats["status"] == 1
     # The adaptive controller takes the reference's step schedule.  The reference problems are chaotic (random weights, T0 up
