@@ -5,7 +5,7 @@ tests/test_gpu_pipeline.py):
   PipelinedPCPredictor  encoder + PC sampler.  `batches_per_launch` consecutive batches share one encoder pass and one sampler
                         launch chain (the sampler's batch-global coupling stays per batch, gp_pc_step_grouped); optionally the
                         encoder of the next group runs on a second HIP stream under the sampler graph of the current one
-                        (`overlap`), and its furthest point sampling always runs ahead on a side stream (`fps_ahead`).
+                        (`overlap`), and its furthest point sampling and ball queries always run ahead on a side stream (`fps_ahead`).
   GroupedODEPredictor   encoder + PF-ODE sampler, several batches per launch of the device-resident RK45 driver, one step
                         controller per batch (gp_rk45_phase_grouped).
   (runner.MultiSequenceTracker does the same for tracking, with ragged groups.)
@@ -105,9 +105,11 @@ class PipelinedPCPredictor:
                 self.s_fps.wait_event(self.ev_enc_done[slot])  # the slot's previous centres are no longer read
                 pts = cat(starts[c])
                 pts.record_stream(self.s_enc)  # allocated here, consumed by the encoder stream
-                enc.sample_centres(pts, slot=slot)
+                # centres AND neighbourhoods: furthest point sampling is a latency-bound chain, the ball queries are LDS / VALU work -
+                # neither touches the matrix pipes the sampler and the SA kernels are bound by
+                ws = enc.prepare_grouping(pts, slot=slot)
                 self.ev_fps[slot].record(self.s_fps)
-            staged[c] = pts
+            staged[c] = (pts, ws)
 
         for e in self.ev_enc_done:
             e.record(self.s_enc)
@@ -121,9 +123,9 @@ class PipelinedPCPredictor:
             with torch.cuda.stream(self.s_enc):
                 self.s_enc.wait_event(self.ev_free[slot])  # the sampler has consumed this slot's previous contents
                 if c in staged:
-                    pts = staged.pop(c)
+                    pts, ws = staged.pop(c)
                     self.s_enc.wait_event(self.ev_fps[slot])
-                    feat = enc.forward(pts, slot=slot, centres_done=True)
+                    feat = enc.forward(pts, slot=slot, grouping=ws)
                 else:
                     pts = cat(i0)
                     feat = enc.forward(pts, slot=slot)
