@@ -475,6 +475,24 @@ __global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncen
     load_ops(0, jn, dcur, zcur);
     jn = load_idx(1);
     float res[Q3];  // running max over the neighbourhood's rows of the pre-bias layer-3 output, per channel 16 n + pt
+    // The weight fragments are read from LDS as ONE software-pipelined stream per 16-row chunk: layer-2 groups (two output chunks of
+    // one k-group: 8 MFMAs) in order (n0, q), then layer-3 groups (four output chunks of one k-group: 16 MFMAs); the fragments of
+    // group g + 1 are requested before the MFMAs of group g, and the scheduling barriers keep them there (hipcc otherwise sinks every
+    // ds_read next to its first use: an LDS round trip in front of every 8 MFMAs).  The first group of the NEXT chunk is requested
+    // under the last group of this one (the weights in LDS never change).
+    constexpr int H2 = (Q2 + 1) / 2, G2 = H2 * Q1, G3 = (Q3 / 4) * Q2;
+    f32x4 w2b[2][2], w3b[2][4];
+    auto ld2 = [&](int g, f32x4 (&w)[2], int lo) {
+        const int n0 = 2 * (g / Q1), q = g % Q1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) w[u] = (n0 + u < Q2) ? w2l[(q * Q2 + n0 + u) * 64 + lo] : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto ld3 = [&](int g, f32x4 (&w)[4], int lo) {
+        const int n0 = 4 * (g / Q2), q = g % Q2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = w3l[(q * Q3 + n0 + u) * 64 + lo];
+    };
+    ld2(0, w2b[0], lane);
 #pragma unroll 1
     for (int it = 0; it < nits; ++it) {
         load_ops(it + 1, jn, dn, zn);
@@ -499,45 +517,53 @@ __global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncen
                 h1[q] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
             }
             // layer 2: two output chunks in flight (independent accumulators hide the 40-cycle dependent MFMA latency)
+            f32x4 acc2[2];
 #pragma unroll
-            for (int n0 = 0; n0 < Q2; n0 += 2) {
-                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int g = 0; g < G2; ++g) {
+                const int n0 = 2 * (g / Q1), q = g % Q1;
+                if (g + 1 < G2)
+                    ld2(g + 1, w2b[(g + 1) & 1], lo);
+                else
+                    ld3(0, w3b[0], lo);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == 0) acc2[0] = acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < Q1; ++q) {
-                    f32x4 wf[2];
+                for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) wf[u] = (n0 + u < Q2) ? w2l[(q * Q2 + n0 + u) * 64 + lo] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int u = 0; u < 2; ++u)
+                        if (n0 + u < Q2) acc2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2b[g & 1][u][jj], h1[q][jj], acc2[u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == Q1 - 1) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            if (n0 + u < Q2) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h1[q][jj], acc[u], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u)
+                        if (n0 + u < Q2) {
+                            f32x4 v = acc2[u] + bb2[n0 + u];
+                            h2[n0 + u] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                        }
                 }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (n0 + u < Q2) {
-                        f32x4 v = acc[u] + bb2[n0 + u];
-                        h2[n0 + u] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-                    }
             }
             // layer 3 + running max over the neighbourhood's chunks: four output chunks in flight
+            f32x4 acc3[4];
 #pragma unroll
-            for (int n0 = 0; n0 < Q3; n0 += 4) {
-                f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int g = 0; g < G3; ++g) {
+                const int n0 = 4 * (g / Q2), q = g % Q2;
+                if (g + 1 < G3)
+                    ld3(g + 1, w3b[(g + 1) & 1], lo);
+                else
+                    ld2(0, w2b[0], lo);  // first group of the next chunk
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == 0) acc3[0] = acc3[1] = acc3[2] = acc3[3] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < Q2; ++q) {
-                    f32x4 wf[4];
+                for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) wf[u] = w3l[(q * Q3 + n0 + u) * 64 + lo];
+                    for (int u = 0; u < 4; ++u) acc3[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[q][jj], w3b[g & 1][u][jj], acc3[u], 0, 0, 0);  // transposed
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == Q2 - 1) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[q][jj], wf[u][jj], acc[u], 0, 0, 0);  // transposed
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float m = points16_max_t(acc[u]);
-                    res[n0 + u] = p == 0 ? m : fmaxf(res[n0 + u], m);
+                    for (int u = 0; u < 4; ++u) {
+                        const float m = points16_max_t(acc3[u]);
+                        res[n0 + u] = p == 0 ? m : fmaxf(res[n0 + u], m);
+                    }
                 }
             }
         }
