@@ -54,7 +54,7 @@ class PCSampler:
             raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                              "run the batches separately")
         self.tile, self.nparts = t_out.value, n_out.value
-        self.kernel_name = f"pc_step_kernel<{self.tile},{self.model}>" if self.tile in (16, 32) else \
+        self.kernel_name = (f"pc_step_kernel<{self.tile}>" if self.model == 0 else f"pc_step_kernel<{self.tile},energy>") if self.tile in (16, 32) else \
             "pc_step_chain_kernel<2>"
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)

@@ -23,5 +23,5 @@ feat = enc.forward(pts); cvec = net.cloud_embed(feat)
 smp = PCSampler(net, B, K, 100, "cuda", use_graph=True)
 x0 = torch.randn(B * K, 9, device="cuda") * 50
 t_pc = timeit(lambda: smp.run(cvec, pts.mean(1), x0), 5)
-print(f"B={B} K={K} GP_SCORE_P={os.environ.get('GP_SCORE_P')} GP_SA_P={os.environ.get('GP_SA_P')}: encoder {t_enc:.3f} ms ({B*2.201/t_enc:.1f} TFLOP/s), "
+print(f"B={B} K={K} ({smp.kernel_name}): encoder {t_enc:.3f} ms ({B*2.201/t_enc:.1f} TFLOP/s), "
       f"PC-100 {t_pc:.3f} ms ({t_pc*10:.1f} us/step, {B*K*0.5335e-3*101/t_pc:.1f} TFLOP/s)")

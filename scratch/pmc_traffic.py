@@ -38,7 +38,7 @@ for spec in sys.argv[2:]:
         shape[short(name)] = {"FETCH_SIZE_KB_per_dispatch": round(f[name][0], 1), "WRITE_SIZE_KB_per_dispatch": round(w.get(name, (0, 0))[0], 1), "dispatches": f[name][1]}
     res["shapes"][f"B={B}"] = shape
     for kname, v in shape.items():
-        if kname.startswith("pc_step_kernel"):
+        if kname.startswith("pc_step"):
             raw = (v["FETCH_SIZE_KB_per_dispatch"] + v["WRITE_SIZE_KB_per_dispatch"]) * 1024
             corr = (2 * v["FETCH_SIZE_KB_per_dispatch"] + v["WRITE_SIZE_KB_per_dispatch"]) * 1024
             alg = R * 216 + 1040 * 1024 + 25 * 1024 + B * 768 * 4 + B * 12  # rows (x, score, 2 x noise in; x, score out) + weights + tvec/biases + cvec + centre

@@ -138,7 +138,7 @@ def test_energy_model_samplers_are_device_resident_and_grouped():
     z1, z2 = torch.randn(n, G * R1, 9, generator=gen), torch.randn(n, G * R1, 9, generator=gen)
     cvec = net.cloud_embed(pf.cuda())
     smp = PCSampler(net, G * B1, K, n, "cuda", use_graph=True, groups=G, model="energy")
-    assert smp.tile == 16 and smp.kernel_name == "pc_step_kernel<16,1>"
+    assert smp.tile == 16 and smp.kernel_name == "pc_step_kernel<16,energy>"
     outs = []
     for _ in range(2):
         _, mean_x = smp.run(cvec, centre.cuda(), init_x.cuda(), z1.cuda(), z2.cuda())
