@@ -62,7 +62,8 @@ SIGNATURES = {
     "gp_rk45_set_dense": [P, P, c_int, P, P],
     "gp_rk45_phase": [c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
     "gp_rk45_phase_grouped": [c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
-    "gp_rk45_phase_model": [c_int, P, c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5
+    "gp_rk45_plan_rows": [c_int, c_int, c_int, c_int],
+    "gp_rk45_phase_model": [c_int, c_int, P, c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5
                            + [c_int, c_int, P, P, c_int, P],
     "gp_rk45_set_dense_grouped": [c_int, P, P, c_int, P, P],
     "gp_rk45_phase_ragged": [c_int, c_int, P, c_int, P, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5

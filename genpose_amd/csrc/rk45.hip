@@ -10,6 +10,7 @@
 // The error norm is the reference's batch-global RMS over all R*9 components: per-tile partial sums, reduced in
 // a fixed order by the single-workgroup decide kernel (deterministic).
 #include "score_bwd.h"
+#include "trunk_chain.h"
 
 namespace {
 
@@ -223,6 +224,112 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
         if (STAGE == 0) {
             const double s1 = block_sum(acc1, sh);
             if (tid == 0) a.partials[a.nblocks + blockIdx.x] = s1;
+        }
+    }
+}
+
+// The same stage in the CHAIN form of the trunk (trunk_chain.h; score model, equal groups, launches of ~32 000 rows and more): a wave
+// carries 16 * PT rows from the stage input to K_s in registers.  Lane (row, g) owns components 4g .. 4g+3 of its row - exactly the
+// B fragment of the first layer - so the f64 stage arithmetic is spread over all lanes with no exchange.
+template <int PT, int STAGE>
+__global__ __launch_bounds__(gp_chain::NT, 1) void rk45_stage_chain_kernel(OdeArgs a, gp_scorenet net) {
+    using C = gp_chain::Cfg<PT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double sh[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pt = lane & 15, g = lane >> 4;
+    const int grp = blockIdx.x / a.bpg, wg_row0 = blockIdx.x * C::ROWS;
+    Rk45State *st = a.st + grp;
+    if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
+    const size_t n = (size_t)a.nrows * POSE;
+    const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
+    const float *tvec = a.tvec + ((size_t)grp * 8 + slot) * HEADS;
+    const double h = st->h;
+    const float sigma = st->stage_sigma[slot];
+    const double g2 = st->stage_g2[slot];
+    const bool commit = STAGE == 1 && st->last_accepted;
+    const int nown = g < 2 ? 4 : (g == 2 ? 1 : 0);  // components 4g .. of a 9-vector this lane owns
+    // ---- stage input: y (+ h * sum_q a_sq K_q) in f64 (requests first, the ring prologue behind them)
+    double yv[PT][4];
+    size_t ge0[PT];
+    bool live[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int row = wg_row0 + (wave * PT + p) * 16 + pt;
+        live[p] = row < a.nrows;
+        const int r = live[p] ? row : a.nrows - 1;  // rows past the end: clamped duplicates (computed, never stored)
+        ge0[p] = (size_t)r * POSE + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            yv[p][c] = 0.0;
+            if (c < nown) {
+                const size_t ge = ge0[p] + c;
+                double v = commit ? a.ynew[ge] : a.y[ge];
+                if (STAGE >= 1 && STAGE <= 6) {
+                    double dy = 0.0;
+#pragma unroll
+                    for (int q = 0; q < STAGE; ++q) {
+                        const double kq = (q == 0 && commit) ? a.K[6 * n + ge] : a.K[(size_t)q * n + ge];
+                        if (q == 0 && commit && live[p]) {  // commit the previous accepted step for this element
+                            a.y[ge] = v;
+                            a.K[ge] = kq;
+                        }
+                        dy += kq * DP_A[STAGE][q];
+                    }
+                    v = v + dy * h;
+                    if (STAGE == 6 && live[p]) a.ynew[ge] = v;
+                } else if (STAGE == 7) {
+                    v = v + st->h0 * st->direction * a.K[ge];
+                }
+                yv[p][c] = v;
+            }
+        }
+    }
+    gp_chain::State<PT> cs;
+    gp_chain::begin<PT>(cs, lds, net, a.cvec, tvec, wg_row0, a.nrows, a.kcand);
+    f32x4 xf[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) xf[p] = f32x4{(float)yv[p][0], (float)yv[p][1], (float)yv[p][2], (float)yv[p][3]};
+    float f[PT][POSE];
+    gp_chain::run<PT>(cs, lds, net, xf, f);
+    double *Kout = a.K + (size_t)(STAGE == 7 ? 1 : (STAGE == 0 ? 0 : (STAGE == 6 ? 6 : STAGE))) * n;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c >= nown || !live[p]) continue;
+            const float fc = g == 0 ? f[p][c] : (g == 1 ? f[p][4 + c] : f[p][8]);
+            const size_t ge = ge0[p] + c;
+            const float rhs = fc / (sigma + 1e-7f);
+            const double kv = 0.0 - (0.5 * g2) * (double)rhs;
+            Kout[ge] = kv;
+            if (STAGE == 0) {
+                const double y0 = a.y[ge];
+                const double sc = st->atol + fabs(y0) * st->rtol;
+                acc0 += (y0 / sc) * (y0 / sc);
+                acc1 += (kv / sc) * (kv / sc);
+            } else if (STAGE == 7) {
+                const double sc = st->atol + fabs(a.y[ge]) * st->rtol;
+                const double d = (kv - a.K[ge]) / sc;
+                acc0 += d * d;
+            } else if (STAGE == 6) {
+                double er = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) er += a.K[(size_t)q * n + ge] * DP_E[q];
+                er += kv * DP_E[6];
+                er *= h;
+                const double yo = a.y[ge], yn = a.ynew[ge];
+                const double sc = st->atol + fmax(fabs(yo), fabs(yn)) * st->rtol;
+                acc0 += (er / sc) * (er / sc);
+            }
+        }
+    }
+    if (STAGE == 0 || STAGE == 6 || STAGE == 7) {
+        const double s0 = block_sum(acc0, sh);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = s0;
+        if (STAGE == 0) {
+            const double s1 = block_sum(acc1, sh);
+            if (threadIdx.x == 0) a.partials[a.nblocks + blockIdx.x] = s1;
         }
     }
 }
@@ -512,13 +619,24 @@ int set_lds_attr(K kern, size_t lds) {
 
 }  // namespace
 
-template <int P, int MODEL>
+// CHAIN: the stage kernels run in the chain form (a.bpg / a.nblocks count 128-row workgroups); the denoising evaluation of phase 5
+// stays on P-row tiles with its own workgroup count
+template <int P, int MODEL, bool CHAIN = false>
 static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double *traj, int traj_cap, double t0, double t_bound, double rtol,
                            double atol, double denoise_scale, int do_denoise, int nstates, const float *centre, double *x_out, hipStream_t st) {
+    static_assert(!CHAIN || MODEL == 0, "the chain form serves the score model");
+    using CC = gp_chain::Cfg<2>;
     const double *y = a.y;
     const size_t lds = MODEL == 0 ? trunk_lds_bytes<P>() : gp_bwd::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
+        if constexpr (CHAIN) {
+            if (set_lds_attr(rk45_stage_chain_kernel<2, 0>, CC::LDS_BYTES) || set_lds_attr(rk45_stage_chain_kernel<2, 1>, CC::LDS_BYTES) ||
+                set_lds_attr(rk45_stage_chain_kernel<2, 2>, CC::LDS_BYTES) || set_lds_attr(rk45_stage_chain_kernel<2, 3>, CC::LDS_BYTES) ||
+                set_lds_attr(rk45_stage_chain_kernel<2, 4>, CC::LDS_BYTES) || set_lds_attr(rk45_stage_chain_kernel<2, 5>, CC::LDS_BYTES) ||
+                set_lds_attr(rk45_stage_chain_kernel<2, 6>, CC::LDS_BYTES) || set_lds_attr(rk45_stage_chain_kernel<2, 7>, CC::LDS_BYTES))
+                return GP_ELAUNCH;
+        }
         if (set_lds_attr(rk45_stage_kernel<P, 0, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 1, MODEL>, lds) ||
             set_lds_attr(rk45_stage_kernel<P, 2, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 3, MODEL>, lds) ||
             set_lds_attr(rk45_stage_kernel<P, 4, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 5, MODEL>, lds) ||
@@ -531,6 +649,13 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
     }
     const dim3 grid(a.nblocks), blk(TrunkCfg<P>::NT), blk1(256);
     const size_t n = (size_t)a.nrows * a.ncomp;
+    auto stage = [&](auto tag) {
+        constexpr int S = decltype(tag)::value;
+        if constexpr (CHAIN)
+            hipLaunchKernelGGL((rk45_stage_chain_kernel<2, S>), grid, dim3(gp_chain::NT), CC::LDS_BYTES, st, a, *net);
+        else
+            hipLaunchKernelGGL((rk45_stage_kernel<P, S, MODEL>), grid, blk, lds, st, a, *net);
+    };
     switch (phase) {
         case 0:
             hipLaunchKernelGGL(rk45_reset_kernel, dim3(a.ngroups), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
@@ -539,7 +664,7 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
         // with ext_sums (a batch sharded over several GPUs) phases 1-3 stop after the per-group sums and phases 11-13 run the
         // controller on the all-reduced sums
         case 1:
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 0, MODEL>), grid, blk, lds, st, a, *net);
+            stage(std::integral_constant<int, 0>{});
             if (a.ext_sums)
                 hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
             else
@@ -550,7 +675,7 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 0);
             break;
         case 2:
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 7, MODEL>), grid, blk, lds, st, a, *net);
+            stage(std::integral_constant<int, 7>{});
             if (a.ext_sums)
                 hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
             else
@@ -561,12 +686,12 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
             break;
         case 3:
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 1, MODEL>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 2, MODEL>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 3, MODEL>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 4, MODEL>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 5, MODEL>), grid, blk, lds, st, a, *net);
-            hipLaunchKernelGGL((rk45_stage_kernel<P, 6, MODEL>), grid, blk, lds, st, a, *net);
+            stage(std::integral_constant<int, 1>{});
+            stage(std::integral_constant<int, 2>{});
+            stage(std::integral_constant<int, 3>{});
+            stage(std::integral_constant<int, 4>{});
+            stage(std::integral_constant<int, 5>{});
+            stage(std::integral_constant<int, 6>{});
             if (a.ext_sums) {
                 hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
                 break;
@@ -587,7 +712,9 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             if constexpr (MODEL == 2) {
                 hipLaunchKernelGGL(rk45_copy_final_kernel, dim3(32, a.ngroups), blk1, 0, st, a, x_out);
             } else {
-                hipLaunchKernelGGL((rk45_finish_kernel<P, MODEL>), grid, blk, lds, st, a, *net, denoise_scale, do_denoise, x_out);
+                OdeArgs af = a;
+                if constexpr (CHAIN) af.bpg = (a.rows_per_group + P - 1) / P, af.nblocks = af.bpg * a.ngroups;
+                hipLaunchKernelGGL((rk45_finish_kernel<P, MODEL>), dim3(af.nblocks), blk, lds, st, af, *net, denoise_scale, do_denoise, x_out);
                 if (traj && nstates > 0)
                     hipLaunchKernelGGL(rk45_traj_post_kernel, dim3(128), blk1, 0, st, a.nrows, a.kcand, nstates, centre, traj);
             }
@@ -638,14 +765,17 @@ int gp_rk45_state_layout(int64_t *out, int n) {
     return GP_OK;
 }
 
-static int ode_args(OdeArgs *a, int *tile, int model, const float *probe, int ngroups, int nclouds_per_group, int k, const float *cvec, const float *tvec,
+static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *probe, int ngroups, int nclouds_per_group, int k, const float *cvec, const float *tvec,
                     const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, float *x32) {
     if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || !cvec || !tvec || !centre || !state || !y || !ynew || !K || !partials) return GP_EINVAL;
     if (model < 0 || model > 2 || (model == 2 && !probe)) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
-    int P = model == 0 ? score_tile_rows(ngroups * rg) : 16;
-    if (ngroups > 1 && rg % P != 0) P = 16;  // tiles must not straddle groups
-    if (ngroups > 1 && rg % P != 0) return GP_EINVAL;
+    // launch plan of the stage kernels (score_trunk.h: score_plan_rows): 16 / 32-row tiles or the 128-row chain form; plan != 0 forces one
+    int P = model == 0 ? (plan ? plan : score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k)) : 16;
+    if (P != 16 && P != 32 && P != 128) return GP_EINVAL;
+    if (model != 0 && P != 16) return GP_EINVAL;
+    if (P == 128 && !gp_chain::Cfg<2>::fits(k)) return GP_EINVAL;
+    if (ngroups > 1 && rg % P != 0) return GP_EINVAL;  // workgroups must not straddle groups
     a->nrows = ngroups * rg, a->kcand = k;
     a->ngroups = ngroups, a->rows_per_group = rg, a->bpg = (rg + P - 1) / P, a->nblocks = a->bpg * ngroups;
     a->blk_info = nullptr, a->grp_info = nullptr;
@@ -669,14 +799,15 @@ static int ode_args(OdeArgs *a, int *tile, int model, const float *probe, int ng
  * ngroups independent batches (nclouds_per_group clouds each, rows / clouds / state laid out group-major) advance with their OWN
  * step controllers - error norm, accept / reject, step size per group, exactly as separate solve_ivp calls - and share every
  * launch; a finished group's workgroups exit at once.  state: ngroups * gp_rk45_state_bytes(); tvec [ngroups][8][768];
- * partials [3][nblocks], nblocks = ngroups * ceil(rows_per_group / tile), tile from gp_pc_tile_rows. */
-int gp_rk45_phase_model(int model, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
+ * partials [3][nblocks], nblocks = ngroups * ceil(rows_per_group / tile), tile from gp_pc_tile_rows (an upper bound: large score-model
+ * launches run the stage kernels in the 128-row chain form, gp_rk45_plan_rows).  plan: 0 = pick, 16 / 32 / 128 = force. */
+int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         const float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
                         double *x_out, double *ext_sums, int ext_rows_per_group, gp_stream_t s) {
     OdeArgs a;
     int P = 0;
-    int rc = ode_args(&a, &P, model, probe, ngroups, nclouds_per_group, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
+    int rc = ode_args(&a, &P, plan, model, probe, ngroups, nclouds_per_group, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
     if (rc != GP_OK || !net) return GP_EINVAL;
     if (ext_sums && ext_rows_per_group < a.rows_per_group) return GP_EINVAL;
     a.ext_sums = ext_sums, a.ext_rows = ext_rows_per_group;
@@ -685,15 +816,25 @@ int gp_rk45_phase_model(int model, const float *probe, int phase, int ngroups, i
     rk45_phase_impl<PP, MM>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out, (hipStream_t)s)
     if (model == 1) return GP_RK45_CALL(16, 1);
     if (model == 2) return GP_RK45_CALL(16, 2);
+    if (P == 128)
+        return rk45_phase_impl<32, 0, true>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                            (hipStream_t)s);
     return P == 16 ? GP_RK45_CALL(16, 0) : GP_RK45_CALL(32, 0);
 #undef GP_RK45_CALL
+}
+
+int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k) {
+    if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || model < 0 || model > 2) return GP_EINVAL;
+    if (model != 0) return 16;
+    const int rg = nclouds_per_group * k;
+    return score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
 }
 
 int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, const float *tvec,
                           const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
                           double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                           gp_stream_t s) {
-    return gp_rk45_phase_model(0, nullptr, phase, ngroups, nclouds_per_group, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap, t0,
+    return gp_rk45_phase_model(0, 0, nullptr, phase, ngroups, nclouds_per_group, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap, t0,
                                t_bound, rtol, atol, denoise_scale, do_denoise, nstates, x_out, nullptr, 0, s);
 }
 

@@ -275,14 +275,16 @@ __device__ __forceinline__ void run(State<PT> &st, float *lds, const gp_scorenet
     }
     // ---- steps 17..64: the three heads (256 -> 256 each) as six half-layers.  Two accumulator sets: while half-layer i accumulates
     // into one, the Linear(256, 3) epilogue of half-layer i - 1 consumes the other, one output chunk per ring step.
-    // The Linear(256, 3) output layer of a head runs on the matrix pipe too: A = its three rows padded to a 16-row fragment (every
-    // lane of row index >= 3 reads the zero row of the LDS table), B = the post-ReLU head activations exactly as the accumulators hold
-    // them; the three outputs of a row land in lane group 0, registers 0..2 - where the caller's lane-group-0 lanes store them.
+    // The Linear(256, 3) output layer of a head runs on the matrix pipe too, as v_mfma_f32_4x4x1_16b_f32 (16 independent 4 x 4 outer
+    // products, 8 cycles): block b = lanes 4b .. 4b+3 = four rows of ONE lane group; A = the head's three rows (+ the zero row of the
+    // LDS table for lane & 3 == 3) at the channel this lane group holds, B = the post-ReLU head activations exactly as the accumulators
+    // hold them.  Lane (row, g) collects the three outputs of its row over the channels of lane group g; the four groups are summed
+    // once at the very end.  (As a zero-padded 16-row v_mfma_f32_16x16x4_f32 operand the same products cost four times the pipe time.)
     f32x4 oacc[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) oacc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     HeadEpi<PT> e;
-    const int m = lane & 15;
+    const int m = lane & 3;
     // epilogue piece of slot k for output chunk n of `done` (a finished half-layer: head hd, half `halfd`)
     auto epi_slot = [&](int k, const f32x4 (&done)[PT][8], int n, int hd, int halfd) {
         const int col = 128 * halfd + 16 * n + 4 * g;  // column within the head
@@ -298,17 +300,17 @@ __device__ __forceinline__ void run(State<PT> &st, float *lds, const gp_scorenet
             }
             if (k == 7 + p) {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) oacc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(e.w0[jj], e.v[p][jj], oacc[p], 0, 0, 0);
+                for (int jj = 0; jj < 4; ++jj) oacc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(e.w0[jj], e.v[p][jj], oacc[p], 0, 0, 0);
             }
         }
     };
-    // output components of head hd (+ bias): valid in lane group 0
+    // this lane group's share of the output components of head hd
     auto finish_head = [&](int hd) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = oacc[p][c] + net.b_out[3 * (hd < 0 ? 0 : hd) + c];
+                const float v = oacc[p][c];
                 // f is a register array: written with compile-time indices, the head selects
                 f[p][c] = hd == 0 ? v : f[p][c];
                 f[p][3 + c] = hd == 1 ? v : f[p][3 + c];
@@ -358,6 +360,16 @@ __device__ __forceinline__ void run(State<PT> &st, float *lds, const gp_scorenet
 #pragma unroll
         for (int k = 0; k < 16; ++k) epi_slot(k, accB, n, 2, 1);
     finish_head(2);
+    // the four lane groups each hold the sum over their quarter of the channels
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+        for (int j = 0; j < POSE; ++j) {
+            float v = f[p][j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            f[p][j] = v + net.b_out[j];
+        }
 }
 
 // component j = 4 g + q of a per-lane 9-vector -> the B fragment of k-group 0 (zero beyond component 8)

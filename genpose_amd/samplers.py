@@ -151,7 +151,7 @@ class ODESampler:
 
     MODELS = {"score": 0, "energy": 1, "likelihood": 2}
 
-    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None, model="score", coupling_group=None):
+    def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None, model="score", coupling_group=None, tile=0):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: every batch keeps its own adaptive
         step control (error norm over ITS rows, accept / reject, step size - what separate cond_ode_sampler calls would do) while
         all of them share each launch (gp_rk45_phase_grouped).
@@ -164,7 +164,10 @@ class ODESampler:
         SHARD of a batch spread over the ranks of the group (equal shards).  scipy's error norm - and the norms of its initial-step
         heuristic - run over the WHOLE batch: after the stage kernels the per-group sums of squares are all-reduced (two doubles per
         group) and the step controller decides on the reduced sums, so every shard takes the accept / reject sequence of the unsharded
-        batch.  On RCCL the all-reduce is captured with the attempts; on gloo the attempts run launch by launch."""
+        batch.  On RCCL the all-reduce is captured with the attempts; on gloo the attempts run launch by launch.
+
+        tile: launch plan of the stage kernels (0 = pick: 16- / 32-row tiles, or the 128-row chain form of the trunk for score-model
+        launches of ~32 000 rows and more, gp_rk45_plan_rows); tests and measurements force one."""
         self.model = self.MODELS[model]
         self.ncomp = 10 if self.model == 2 else 9
         self.ragged = group_clouds is not None
@@ -186,9 +189,11 @@ class ODESampler:
         self.net, self.B, self.K, self.groups = net, B, K, groups
         R = self.R = B * K
         if not self.ragged:
-            self.tile = _lib.lib().gp_pc_tile_rows(groups, B // groups, K) if self.model == 0 else 16  # the backward pass runs on 16-row tiles
-            if self.tile < 0 or (groups > 1 and (R // groups) % self.tile):
-                raise ValueError(f"{B // groups} clouds x {K} candidates per batch is not a multiple of the 16-row tile; run the batches separately")
+            # the backward pass (energy model, likelihood) runs on 16-row tiles
+            self.tile = int(tile) if tile else _lib.lib().gp_rk45_plan_rows(self.model, groups, B // groups, K)
+            if self.tile not in (16, 32, 128) or (self.model != 0 and self.tile != 16) or (groups > 1 and (R // groups) % self.tile):
+                raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
+                                 "run the batches separately")
             self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
         if self.ragged:
             self.set_groups(group_clouds)
@@ -263,12 +268,12 @@ class ODESampler:
             _lib.call("gp_rk45_phase_ragged", phase, self.groups, ptr(self.grp_info), self.nblocks, ptr(self.blk_info), self.tile, self.B, self.K,
                       self.net.w.ref(), *tail)
         else:
-            _lib.call("gp_rk45_phase_model", self.model, ptr(self.probe), phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail[:-1],
+            _lib.call("gp_rk45_phase_model", self.model, self.tile, ptr(self.probe), phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail[:-1],
                       ptr(self.ext_sums), self.ext_rows, tail[-1])
             if self.ext_sums is not None and phase in (1, 2, 3):
                 # sharded batch: the controller decides on the sums of squares over ALL shards
                 self._dist.all_reduce(self.ext_sums, op=self._dist.ReduceOp.SUM, group=self.coupling_group)
-                _lib.call("gp_rk45_phase_model", self.model, ptr(self.probe), phase + 10, self.groups, self.B // self.groups, self.K, self.net.w.ref(),
+                _lib.call("gp_rk45_phase_model", self.model, self.tile, ptr(self.probe), phase + 10, self.groups, self.B // self.groups, self.K, self.net.w.ref(),
                           *tail[:-1], ptr(self.ext_sums), self.ext_rows, tail[-1])
 
     def _embed(self):

@@ -291,8 +291,11 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
  * f64) and ext_rows_per_group = rows of a group over all ranks.  Phases 1, 2, 3 then stop after writing this rank's per-group sums of
  * squares to ext_sums; the caller all-reduces ext_sums (RCCL: capturable with the launches) and runs phase 11, 12 or 13 = the step
  * controller on the reduced sums (+ trajectory record).  Every shard then takes the accept / reject sequence of the unsharded batch.
- * ext_sums = NULL: the controller reduces the local partials itself (phases 11-13 are GP_EINVAL). */
-int gp_rk45_phase_model(int model, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
+ * ext_sums = NULL: the controller reduces the local partials itself (phases 11-13 are GP_EINVAL).
+ * plan: rows per workgroup of the stage kernels - 16 / 32 = tile form, 128 = the chain form of the trunk (score model only; k >= 43,
+ * rows_per_group % 128 == 0 when ngroups > 1); 0 = gp_rk45_plan_rows() picks.  partials [3][ngroups * ceil(rows_per_group / plan)]. */
+int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k);
+int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         const float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
                         double *x_out, double *ext_sums, int ext_rows_per_group, gp_stream_t s);

@@ -95,3 +95,32 @@ def test_pc_sampler_chain_vs_oracle(nets, G, B1, K, n):
     _, m32 = smp32.run(cvec, centre.cuda(), init_x.cuda(), z1.cuda(), z2.cuda())
     torch.cuda.synchronize()
     np.testing.assert_allclose(got.numpy(), m32.cpu().numpy(), rtol=0, atol=2e-5 * float(got.abs().max()))
+
+
+def test_ode_stage_kernels_chain_vs_tile_form(nets):
+    """RK45 stage kernels in the chain form (rk45_stage_chain_kernel) against the tile form: two batches per launch (each with its own
+    step controller), T0 = 0.55 as benched - the same accept / reject sequence, evaluation count and poses; and one ragged batch."""
+    from genpose_amd.samplers import ODESampler
+    snet, _ = nets
+    for groups, B in ((2, 128), (1, 45)):  # 2 x 3200 rows; 2250 rows: a ragged last workgroup
+        K = 50
+        gen = torch.Generator().manual_seed(groups)
+        cvec = torch.randn(B, 768, generator=gen).cuda()
+        centre = torch.randn(B, 3, generator=gen).cuda()
+        x0 = torch.randn(B * K, 9, generator=gen).cuda()
+        res = {}
+        for tile in (32, CHAIN):
+            smp = ODESampler(snet, B, K, "cuda", groups=groups, tile=tile)
+            assert smp.tile == tile
+            _, x = smp.run(cvec, centre, x0, T0=0.55)
+            counts = [(g["nfev"], g["n_attempts"], g["n_accepted"]) for g in smp.group_stats]
+            res[tile] = (x.cpu().numpy(), counts)
+        a, b = res[32], res[CHAIN]
+        assert np.isfinite(b[0]).all() and len(b[1]) == groups
+        assert a[1] == b[1], (a[1], b[1])
+        np.testing.assert_allclose(b[0][:, :6], a[0][:, :6], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(b[0][:, 6:], a[0][:, 6:], rtol=0, atol=2e-4 * np.abs(a[0][:, 6:]).max())
+    with pytest.raises(ValueError):
+        ODESampler(snet, 6, 50, "cuda", groups=2, tile=CHAIN)  # 150 rows per batch
+    assert ODESampler(snet, 64, 50, "cuda").tile in (16, 32) and ODESampler(snet, 640, 50, "cuda", groups=10).tile in (32, CHAIN)
+
