@@ -71,7 +71,8 @@ struct OdeArgs {
     // ragged groups (different numbers of clouds per group; null = equal groups): per workgroup {group, first row, end row},
     // per group {first workgroup, workgroups, rows, first row}
     const int *blk_info, *grp_info;
-    const float *cvec, *tvec;  // tvec [ngroups][8][768] (slot-indexed like stage_t)
+    const float *cvec;
+    float *tvec;               // [ngroups][8][768] time embedding per stage slot (slot-indexed like stage_t), written by the controller kernels
     const float *centre;
     Rk45State *st;
     double *y, *ynew, *K;      // y, ynew [R*9]; K [7][R*9]
@@ -340,7 +341,48 @@ __device__ __forceinline__ double sum_partials(const double *p, int nb, double *
     return block_sum(s, sh);
 }
 
-// Prepare the next attempt: clamp the step to t_bound and publish the six stage times (rk.py:119-142).
+// Time embedding of stage slots [lo, lo + gridDim.x) of every group, straight from the solver states, launched by the phase functions
+// right behind the kernel that decided the stage times: tvec[slot] = W1t . relu(Wt1 . [sin(x), cos(x)] + bt1), x = t * W * 2 pi
+// (scorenet.py:55-64,111-116) - the arithmetic of time_embed_kernel (scorenet.hip), every output an fmaf chain in k order, so the rows
+// equal that kernel's bit for bit.  grid (slots, ngroups, 3 / PER): one slot and PER x 256 of the 768 outputs per workgroup.  With few
+// groups the kernel is pure latency: a third of the outputs per workgroup (the hidden layer recomputed by each), a group's six slots
+// over 18 CUs, the k loops unrolled so that all their loads are in flight at once; with many groups (tracking: one per sequence)
+// it is throughput-bound and one workgroup per slot does all 768 (fused into the one-workgroup-per-group controller it was
+// VALU- and latency-bound on a single CU: 21-54 us per attempt against 10 + 6 for controller + this kernel).
+template <int UNROLL, int PER>  // PER outputs per thread: gridDim.z = 3 / PER
+__global__ __launch_bounds__(256) void rk45_embed_kernel(const Rk45State *st, int lo, gp_scorenet net, float *tvec) {
+    __shared__ float four[128], tf[128];
+    st += blockIdx.y;
+    if (lo > 0 && st->status != 0) return;  // finished (or failed): no further stage runs for this group
+    const int tid = threadIdx.x, slot = lo + blockIdx.x;
+    const float tv = st->stage_t[slot];
+    if (tid < 64) {
+        const float xp = ((tv * net.fourier_w[tid]) * 2.0f) * 3.14159274101257324f;  // f32 evaluation order of the reference
+        four[tid] = sinf(xp);
+        four[tid + 64] = cosf(xp);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float acc = 0.f;
+        const float *w = net.w_t1 + tid;
+#pragma unroll UNROLL
+        for (int k = 0; k < 128; ++k) acc = fmaf(four[k], w[k * 128], acc);
+        tf[tid] = fmaxf(acc + net.b_t1[tid], 0.f);
+    }
+    __syncthreads();
+    float acc[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) acc[u] = 0.f;
+    const float *w = net.w_headt + 256 * PER * blockIdx.z + tid;
+#pragma unroll UNROLL
+    for (int k = 0; k < 128; ++k)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) acc[u] = fmaf(tf[k], w[k * HEADS + 256 * u], acc[u]);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) tvec[((size_t)blockIdx.y * 8 + slot) * HEADS + 256 * (PER * blockIdx.z + u) + tid] = acc[u];
+}
+
+// Prepare the next attempt: clamp the step to t_bound (rk.py:119-142) - thread 0 ...
 __device__ void begin_attempt(Rk45State *st) {
     const double t = st->t, dir = st->direction;
     const double min_step = 10.0 * fabs(nextafter(t, dir * INFINITY) - t);
@@ -358,7 +400,12 @@ __device__ void begin_attempt(Rk45State *st) {
     st->t_new = t_new;
     st->h = h;
     st->h_abs = fabs(h);
-    for (int s = 1; s <= 6; ++s) set_stage(st, s, t + DP_C[s] * h);
+}
+// ... and the six stage times, one thread each (f64 pow / log per slot)
+__device__ void publish_attempt(Rk45State *st) {
+    __syncthreads();  // thread 0's controller state is visible
+    if (st->status != 0) return;  // finished or failed (uniform): no further stage runs
+    if (threadIdx.x < 6) set_stage(st, threadIdx.x + 1, st->t + DP_C[threadIdx.x + 1] * st->h);
 }
 
 // mode 0: after f0 (d0, d1 -> h0, stage slot 0 = t0 + h0*dir);  mode 1: after f1 (d2 -> h_abs, first attempt);
@@ -405,6 +452,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
             st->step_rejected = 0;
             begin_attempt(st);
         }
+        publish_attempt(st);
     } else {
         if (st->status != 0) return;
         const double s0 = a.ext_sums ? a.ext_sums[blockIdx.x] : sum_partials(part, nblk, sh);
@@ -447,6 +495,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
             st->h_abs = h_abs;
             if (st->status == 0) begin_attempt(st);
         }
+        publish_attempt(st);
     }
 }
 
@@ -580,9 +629,7 @@ __global__ void rk45_traj_post_kernel(int nrows, int kcand, int nstates, const f
     }
 }
 
-__global__ void rk45_reset_kernel(Rk45State *st, double t0, double t_bound, double rtol, double atol, int traj_cap, double eps_time) {
-    if (threadIdx.x != 0) return;
-    st += blockIdx.x;  // one block per group
+__device__ void reset_state(Rk45State *st, double t0, double t_bound, double rtol, double atol, int traj_cap) {
     st->t = t0, st->t_bound = t_bound, st->direction = t_bound >= t0 ? 1.0 : -1.0;
     st->rtol = rtol, st->atol = atol;
     st->h = 0, st->h_abs = 0, st->d0 = st->d1 = st->h0 = 0, st->err_norm = 0;
@@ -593,7 +640,9 @@ __global__ void rk45_reset_kernel(Rk45State *st, double t0, double t_bound, doub
     // the f64 formula differs by <= 1e-7 relative - documented deviation.
     for (int i = 0; i < 8; ++i) st->stage_t[i] = 0.f, st->stage_sigma[i] = 1.f, st->stage_g2[i] = 0.0;
     set_stage(st, 0, t0);
-    (void)eps_time;
+}
+__global__ void rk45_reset_kernel(Rk45State *st, double t0, double t_bound, double rtol, double atol, int traj_cap) {
+    if (threadIdx.x == 0) reset_state(st + blockIdx.x, t0, t_bound, rtol, atol, traj_cap);  // one block per group
 }
 
 struct DenseP {
@@ -649,6 +698,13 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
     }
     const dim3 grid(a.nblocks), blk(TrunkCfg<P>::NT), blk1(256);
     const size_t n = (size_t)a.nrows * a.ncomp;
+    // time embeddings of stage slots [lo, lo + n) of every group, behind the kernel that decided their times
+    auto embed = [&](int lo, int n) {
+        if (n * a.ngroups * 3 <= 256)
+            hipLaunchKernelGGL((rk45_embed_kernel<64, 1>), dim3(n, a.ngroups, 3), blk1, 0, st, a.st, lo, *net, a.tvec);
+        else
+            hipLaunchKernelGGL((rk45_embed_kernel<4, 3>), dim3(n, a.ngroups, 1), blk1, 0, st, a.st, lo, *net, a.tvec);
+    };
     auto stage = [&](auto tag) {
         constexpr int S = decltype(tag)::value;
         if constexpr (CHAIN)
@@ -658,7 +714,8 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
     };
     switch (phase) {
         case 0:
-            hipLaunchKernelGGL(rk45_reset_kernel, dim3(a.ngroups), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap, 0.0);
+            hipLaunchKernelGGL(rk45_reset_kernel, dim3(a.ngroups), dim3(64), 0, st, a.st, t0, t_bound, rtol, atol, traj_cap);
+            embed(0, 1);
             if (traj && hipMemcpyAsync(traj, y, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return GP_ELAUNCH;
             break;
         // with ext_sums (a batch sharded over several GPUs) phases 1-3 stop after the per-group sums and phases 11-13 run the
@@ -669,10 +726,12 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
                 hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
             else
                 hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 0);
+            embed(0, 1);
             break;
         case 11:
             if (!a.ext_sums) return GP_EINVAL;
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 0);
+            embed(0, 1);
             break;
         case 2:
             stage(std::integral_constant<int, 7>{});
@@ -680,10 +739,12 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
                 hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
             else
                 hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
+            embed(1, 6);
             break;
         case 12:
             if (!a.ext_sums) return GP_EINVAL;
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
+            embed(1, 6);
             break;
         case 3:
             stage(std::integral_constant<int, 1>{});
@@ -697,15 +758,18 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
                 break;
             }
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
+            embed(1, 6);
             if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64, a.ngroups), blk1, 0, st, a);
             break;
         case 13:
             if (!a.ext_sums) return GP_EINVAL;
             hipLaunchKernelGGL(rk45_decide_kernel, dim3(a.ngroups), blk1, 0, st, a, 2);
+            embed(1, 6);
             if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64, a.ngroups), blk1, 0, st, a);
             break;
         case 4:
             hipLaunchKernelGGL(rk45_set_slot0_kernel, dim3(a.ngroups), dim3(64), 0, st, a.st, t0);
+            embed(0, 1);
             break;
         case 5:
             if (!x_out) return GP_EINVAL;
@@ -765,7 +829,7 @@ int gp_rk45_state_layout(int64_t *out, int n) {
     return GP_OK;
 }
 
-static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *probe, int ngroups, int nclouds_per_group, int k, const float *cvec, const float *tvec,
+static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *probe, int ngroups, int nclouds_per_group, int k, const float *cvec, float *tvec,
                     const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, float *x32) {
     if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || !cvec || !tvec || !centre || !state || !y || !ynew || !K || !partials) return GP_EINVAL;
     if (model < 0 || model > 2 || (model == 2 && !probe)) return GP_EINVAL;
@@ -789,20 +853,20 @@ static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *pro
 
 /* Phase driver.  Every phase is a fixed launch sequence on stream s (graph-capturable):
  *   phase 0: reset state (t0 -> t_bound), y must hold y0; copies y0 into traj slot 0 when traj != NULL
- *   phase 1: f0 + d0/d1 -> h0          [needs tvec slot 0 = time_embed(stage_t[0]) BEFORE it]
+ *   phase 1: f0 + d0/d1 -> h0
  *   phase 2: f1 + d2 -> h_abs, first attempt's stage times
  *   phase 3: one attempt: 6 stage kernels + decide + record
  *   phase 4: set slot 0 to `eps_t` (denoise evaluation time)
  *   phase 5: finish: denoise + normalise + centre -> x_out [R,9] f64; post-process nstates trajectory states
- * Between phases the caller runs gp_time_embed_strided(8, ngroups, gp_rk45_state_bytes()/4, net, stage_times_dev, tvec) where
- * stage_times_dev points at group 0's Rk45State.stage_t (offset from gp_rk45_state_layout).
+ * tvec [ngroups][8][768] is scratch owned by the solver: every kernel that decides stage times (reset, the step controller, phase 4)
+ * also writes their time embeddings there (the arithmetic of gp_time_embed), so no launch separates the controller from the next stage.
  * ngroups independent batches (nclouds_per_group clouds each, rows / clouds / state laid out group-major) advance with their OWN
  * step controllers - error norm, accept / reject, step size per group, exactly as separate solve_ivp calls - and share every
  * launch; a finished group's workgroups exit at once.  state: ngroups * gp_rk45_state_bytes(); tvec [ngroups][8][768];
  * partials [3][nblocks], nblocks = ngroups * ceil(rows_per_group / tile), tile from gp_pc_tile_rows (an upper bound: large score-model
  * launches run the stage kernels in the 128-row chain form, gp_rk45_plan_rows).  plan: 0 = pick, 16 / 32 / 128 = force. */
 int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
-                        const float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
+                        float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
                         double *x_out, double *ext_sums, int ext_rows_per_group, gp_stream_t s) {
     OdeArgs a;
@@ -830,7 +894,7 @@ int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k) {
     return score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
 }
 
-int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, const float *tvec,
+int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, float *tvec,
                           const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
                           double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                           gp_stream_t s) {
@@ -839,7 +903,7 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
 }
 
 int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nblocks, const int32_t *blk_info, int tile, int nclouds_total, int k,
-                         const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state, double *y, double *ynew,
+                         const gp_scorenet *net, const float *cvec, float *tvec, const float *centre, void *state, double *y, double *ynew,
                          double *K, double *partials, double *traj, int traj_cap, double t0, double t_bound, double rtol, double atol,
                          double denoise_scale, int do_denoise, int nstates, double *x_out, gp_stream_t s) {
     if (ngroups <= 0 || nblocks <= 0 || !grp_info || !blk_info || (tile != 16 && tile != 32) || nclouds_total <= 0 || k <= 0 || !net || !cvec ||
@@ -859,7 +923,7 @@ int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nb
                                                (hipStream_t)s);
 }
 
-int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state,
+int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, float *tvec, const float *centre, void *state,
                   double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap, double t0, double t_bound, double rtol,
                   double atol, double denoise_scale, int do_denoise, int nstates, double *x_out, gp_stream_t s) {
     return gp_rk45_phase_grouped(phase, 1, nclouds, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap, t0, t_bound, rtol, atol,

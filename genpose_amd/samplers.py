@@ -276,13 +276,9 @@ class ODESampler:
                 _lib.call("gp_rk45_phase_model", self.model, self.tile, ptr(self.probe), phase + 10, self.groups, self.B // self.groups, self.K, self.net.w.ref(),
                           *tail[:-1], ptr(self.ext_sums), self.ext_rows, tail[-1])
 
-    def _embed(self):
-        import ctypes
-        stage_t = ctypes.c_void_p(self.state.data_ptr() + self.layout["stage_t"])
-        _lib.call("gp_time_embed_strided", 8, self.groups, self.state_bytes // 4, self.net.w.ref(), stage_t, ptr(self.tvec), stream_ptr())
-
     def _attempt(self, traj):
-        self._embed()
+        # the step controller at the end of phase 3 (and of phase 2 before the first attempt) also writes the time embeddings of the
+        # next attempt's six stage times: an attempt is six stage launches + one controller launch
         self._phase(3, traj)
 
     def _read_states(self):
@@ -365,9 +361,7 @@ class ODESampler:
         y0[:, :9].copy_(x.double())   # solve_ivp casts the initial state to float64
         y0[:, 9].zero_()
         self._phase(0, None, t0=eps, t_bound=1.0, rtol=rtol, atol=atol)
-        self._embed()
         self._phase(1, None)
-        self._embed()
         self._phase(2, None)
         sts = self._solve(None, "graph", eps, max_attempts)
         self._phase(5, None)
@@ -414,15 +408,12 @@ class ODESampler:
                     self.traj = torch.zeros(self.TRAJ_CAP, self.R * 9, dtype=torch.float64, device=self.dev)
                 traj = self.traj
             self._phase(0, traj, t0=T0, t_bound=eps, rtol=rtol, atol=atol)
-        self._embed()
         self._phase(1, traj)
-        self._embed()
         self._phase(2, traj)
         gname = "graph_dense" if dense else ("graph_traj" if traj is not None else "graph")
         sts = self._solve(traj, gname, T0, max_attempts)
         st = sts[0]
         self._phase(4, traj, t0=eps)
-        self._embed()
         nstates = (num_steps if dense else int(st["n_accepted"]) + 1) if traj is not None else 0
         if traj is not None and not dense and nstates > self.TRAJ_CAP:
             raise RuntimeError(f"ODE sampler: {nstates} accepted states exceed the trajectory capacity {self.TRAJ_CAP}")

@@ -256,14 +256,15 @@ int gp_pc_step_coupled(int ngroups, int nclouds_per_group, int k, int step, int 
  *   4 set evaluation slot 0 to time `t0` (the denoise evaluation at eps)
  *   5 finish: denoise step (samplers.py:209-218) with scale `denoise_scale`, normalize_rotation, + centre -> x_out [R,9] f64,
  *     and the same post-processing of the first `nstates` trajectory states.
- * Before phases 1, 2, every 3 and 5 the caller refreshes tvec = gp_time_embed(8, net, state + offset(stage_t), tvec). */
+ * tvec is scratch owned by the solver: every kernel that decides stage times (reset, step controller, phase 4) writes their time
+ * embeddings there itself (the arithmetic of gp_time_embed), so no launch separates the controller from the next stage kernel. */
 int64_t gp_rk45_state_bytes(void);
 /* Dense-output mode = solve_ivp(..., t_eval=np.linspace(T0, eps, n)) (samplers.py:201-205): call after phase 0 with traj = NULL
  * there; t_eval_dev [n_eval] f64 on the device, P_host = RK45's 7x4 dense-output matrix (row-major, HOST memory).  traj
  * [n_eval][R*9] then receives the 4th-order interpolant at every t_eval point (scipy RkDenseOutput). */
 int gp_rk45_set_dense(void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s);
 int gp_rk45_state_layout(int64_t *offsets, int n); /* n >= 13: t,h_abs,status,n_attempts,n_accepted,nfev,err_norm,log_t,log_h,log_err,log_acc,stage_t,last_accepted */
-int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre,
+int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const float *cvec, float *tvec, const float *centre,
                   void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap, double t0,
                   double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                   gp_stream_t s);
@@ -271,10 +272,10 @@ int gp_rk45_phase(int phase, int nclouds, int k, const gp_scorenet *net, const f
 /* The same driver over `ngroups` independent batches that share every launch while keeping their OWN step controllers (error norm,
  * accept / reject and step size per group, exactly as separate solve_ivp calls); a finished group's workgroups exit at once.
  * Rows, clouds and solver states are laid out group-major: state = ngroups * gp_rk45_state_bytes(), tvec [ngroups][8][768]
- * (gp_time_embed_strided(8, ngroups, gp_rk45_state_bytes() / 4, net, &state[0].stage_t, tvec)), partials [3][nblocks] with
+ * (scratch), partials [3][nblocks] with
  * nblocks = ngroups * ceil(rows_per_group / tile), tile = gp_pc_tile_rows(ngroups, nclouds_per_group, k) (rows of a group must be
  * a multiple of it).  traj: every group writes its own rows at its own accepted-step slot. */
-int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, const float *tvec,
+int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, float *tvec,
                           const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
                           double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                           gp_stream_t s);
@@ -296,7 +297,7 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
  * rows_per_group % 128 == 0 when ngroups > 1); 0 = gp_rk45_plan_rows() picks.  partials [3][ngroups * ceil(rows_per_group / plan)]. */
 int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k);
 int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
-                        const float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
+                        float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
                         double *x_out, double *ext_sums, int ext_rows_per_group, gp_stream_t s);
 /* Ragged variant: groups with different numbers of clouds (tracking: the objects of one frame form a group, frames of different
@@ -304,7 +305,7 @@ int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int 
  * {group, first row, end row (exclusive) of the group} per workgroup of `tile` (16 or 32) rows; both device int32.  Rows stay
  * cloud-major (k rows per cloud), groups occupy consecutive row ranges. */
 int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nblocks, const int32_t *blk_info, int tile, int nclouds_total, int k,
-                         const gp_scorenet *net, const float *cvec, const float *tvec, const float *centre, void *state, double *y, double *ynew,
+                         const gp_scorenet *net, const float *cvec, float *tvec, const float *centre, void *state, double *y, double *ynew,
                          double *K, double *partials, double *traj, int traj_cap, double t0, double t_bound, double rtol, double atol,
                          double denoise_scale, int do_denoise, int nstates, double *x_out, gp_stream_t s);
 int gp_rk45_set_dense_grouped(int ngroups, void *state, const double *t_eval_dev, int n_eval, const double *P_host, gp_stream_t s);
