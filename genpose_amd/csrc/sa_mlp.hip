@@ -187,6 +187,119 @@ __global__ __launch_bounds__(256) void point_linear_kernel(int M, int K, int N, 
     }
 }
 
+
+// The same GEMM with the WEIGHTS STATIONARY IN REGISTERS, for the three shapes of the light encoder (rows x K -> N: B*512 x 96 -> 128,
+// B*256 x 256 -> 256, B*128 x 512 -> 512).  The kernel above re-reads every weight fragment from the L2 for each 64-row tile and
+// is latency-bound on that stream (0.34 / 0.51 / 0.66 of the MFMA peak on the three levels).  Here a wave keeps the A fragments of
+// NCW output chunks x all KB k-blocks in registers for the whole launch (48 / 128 / 128 registers), the workgroup's four waves (and
+// blockIdx.y) split the output channels, and persistent workgroups stream 16 * PT-row tiles of X through LDS: with PF the next tile
+// is requested into registers before the current one is multiplied (the scheduling barrier keeps the requests there) and written to
+// LDS behind it; WGS workgroups per CU fill each other's barrier bubbles.  The MFMA order per output (k-block major, jj inner) is
+// the kernel above's: the results are bit-identical.
+template <int KB, int NCW, int PT, bool PF, int WGS>
+__global__ __launch_bounds__(256, WGS) void point_linear_ws_kernel(int M, int N, const float *__restrict__ X, const float *__restrict__ Wp,
+                                                                 float *__restrict__ Z, int ntiles) {
+    constexpr int K = 16 * KB, LD = K + GP_LD_PAD, R = 16 * PT;
+    constexpr int PRE = R * (K / 4) / 256;  // f32x4 per thread and tile
+    static_assert(R * (K / 4) % 256 == 0, "tile size");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NC = N / 16, c0 = (blockIdx.y * 4 + wave) * NCW;
+    f32x4 wr[NCW][KB];
+#pragma unroll
+    for (int c = 0; c < NCW; ++c)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) wr[c][kb] = reinterpret_cast<const f32x4 *>(Wp)[((size_t)kb * NC + c0 + c) * 64 + lane];
+    f32x4 pre[PF ? PRE : 1];
+    auto request = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int e = tid + u * 256, r = e / (K / 4), q = e - r * (K / 4);
+            int g = t * R + r;
+            g = g < M ? g : M - 1;
+            pre[u] = *reinterpret_cast<const f32x4 *>(X + (size_t)g * K + 4 * q);
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int e = tid + u * 256, r = e / (K / 4), q = e - r * (K / 4);
+            *reinterpret_cast<f32x4 *>(lds + r * LD + 4 * q) = pre[u];
+        }
+    };
+    int t = blockIdx.x;
+    if constexpr (PF) {
+        if (t < ntiles) request(t);
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        __syncthreads();  // every wave has read the previous tile
+        if constexpr (PF) {
+            deposit();
+        } else {  // no register budget for a tile in flight: the co-resident workgroup covers this one's load
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) {
+                const int e = tid + u * 256, r = e / (K / 4), q = e - r * (K / 4);
+                int g = t * R + r;
+                g = g < M ? g : M - 1;
+                *reinterpret_cast<f32x4 *>(lds + r * LD + 4 * q) = *reinterpret_cast<const f32x4 *>(X + (size_t)g * K + 4 * q);
+            }
+        }
+        __syncthreads();
+        if constexpr (PF) {
+            if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 acc[NCW][PT];
+#pragma unroll
+        for (int c = 0; c < NCW; ++c)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *xb = lds + (lane & 15) * LD + 4 * (lane >> 4);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            f32x4 b[PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) b[p] = *reinterpret_cast<const f32x4 *>(xb + p * 16 * LD + kb * 16);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int c = 0; c < NCW; ++c)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[c][kb][jj], b[p][jj], acc[c][p], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) {
+            const int ch = (c0 + c) * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int row = t * R + p * 16 + (lane & 15);
+                if (row < M) *reinterpret_cast<f32x4 *>(Z + (size_t)row * N + ch) = acc[c][p];
+            }
+        }
+    }
+}
+
+template <int KB, int NCW, int PT, bool PF, int WGS>
+int launch_point_linear_ws(int rows, int n_out, const float *x, const float *wpack, float *z, hipStream_t st) {
+    constexpr int K = 16 * KB, R = 16 * PT;
+    constexpr size_t lds = (size_t)R * (K + GP_LD_PAD) * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(point_linear_ws_kernel<KB, NCW, PT, PF, WGS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return GP_ELAUNCH;
+        done = true;
+    }
+    const int ntiles = (rows + R - 1) / R, nsplit = n_out / (64 * NCW);
+    // persistent: WGS workgroups per CU over all channel splits, so that the splits of a tile run side by side and share its rows in the
+    // L2 (a multiple of 8 in x keeps them on one XCD: the linear workgroup index is dealt round-robin over the eight)
+    int gx = 256 * WGS / nsplit;
+    gx = ntiles < gx ? ntiles : gx;
+    if (gx >= 8) gx &= ~7;
+    hipLaunchKernelGGL((point_linear_ws_kernel<KB, NCW, PT, PF, WGS>), dim3(gx, nsplit), dim3(256), lds, st, rows, n_out, x, wpack, z, ntiles);
+    return gp_launch_status();
+}
+
 struct SAPreArgs {
     int n, np, ns, c1, c2, c3, zstride, zoff;
     const float *xyz, *new_xyz, *z;  // z [b, n, zstride] or null (level 0: no input features)
@@ -851,6 +964,12 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
 int gp_point_linear(int rows, int k_in, int n_out, const float *x, const float *wpack, float *z, gp_stream_t s) {
     if (rows < 0 || k_in <= 0 || (k_in & 3) || n_out <= 0 || (n_out & 3) || !x || !wpack || !z) return GP_EINVAL;
     if (rows == 0) return GP_OK;
+    // the shapes of the light encoder run with the weights stationary in registers
+    // <k-blocks, chunks per wave, 16-row fragments per tile, tile in flight in registers, workgroups per CU>: measured best of
+    // the variants that fit the register file (320 clouds: 43 / 93 / 179 us against 76 / 133 / 236 us for the kernel below)
+    if (k_in == 96 && n_out == 128) return launch_point_linear_ws<6, 2, 2, true, 4>(rows, n_out, x, wpack, z, (hipStream_t)s);
+    if (k_in == 256 && n_out == 256) return launch_point_linear_ws<16, 2, 2, true, 2>(rows, n_out, x, wpack, z, (hipStream_t)s);
+    if (k_in == 512 && n_out == 512) return launch_point_linear_ws<32, 1, 2, false, 2>(rows, n_out, x, wpack, z, (hipStream_t)s);
     const size_t lds = (size_t)64 * (gp_round16(k_in) + GP_LD_PAD) * sizeof(float);
     if (lds > 160 * 1024) return GP_EINVAL;
     if (lds > 64 * 1024) {

@@ -70,3 +70,26 @@ def test_unsupported_shapes_fail_loudly():
     with pytest.raises(_lib.GenposeHipError):  # nsample 8 (the reference's 'dense' config, level 2) is not a multiple of 16
         _lib.call("gp_sa_mlp_max", 1, 64, 8, 8, 0, 16, 16, 32, ptr(x), None, ptr(x), ptr(idx), ptr(w), ptr(w), ptr(w), ptr(w), ptr(w), ptr(w),
                   ptr(out), 32, 0, stream_ptr())
+
+
+@pytest.mark.parametrize("k_in,n_out", [(96, 128), (256, 256), (512, 512), (64, 96)])
+@pytest.mark.parametrize("rows", [1, 37, 4096 + 19])
+def test_point_linear_vs_fp32_reference(k_in, n_out, rows):
+    """gp_point_linear (hoisted feature half of a first layer: Z = X W^T) against the plain fp32 product, for the three shapes that
+    run with the weights stationary in registers (ragged last tiles, fewer tiles than workgroups) and one that takes the generic
+    kernel.  fp32 tolerance: 2e-6 of the largest output (k <= 512 products per output)."""
+    from genpose_amd import _lib
+    from genpose_amd._lib import ptr, stream_ptr
+    from genpose_amd.weights import pack_weight
+    gen = torch.Generator().manual_seed(rows + k_in)
+    X = torch.randn(rows, k_in, generator=gen)
+    W = torch.randn(n_out, k_in, generator=gen) / k_in ** 0.5
+    wp = pack_weight(W).cuda()
+    x_d = X.cuda()
+    z = torch.full((rows + 1, n_out), 7.0, device="cuda")  # one guard row behind the output
+    _lib.call("gp_point_linear", rows, k_in, n_out, ptr(x_d), ptr(wp), ptr(z), stream_ptr())
+    torch.cuda.synchronize()
+    ref = (X.double() @ W.double().T).float().numpy()
+    got = z.cpu().numpy()
+    assert (got[rows] == 7.0).all(), "wrote past the last row"
+    np.testing.assert_allclose(got[:rows], ref, rtol=0, atol=2e-6 * np.abs(ref).max() * (k_in / 96) ** 0.5 + 1e-6)
