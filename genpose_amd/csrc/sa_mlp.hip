@@ -722,9 +722,13 @@ int launch_chain_lds(const SAPreArgs &a, int b, hipStream_t st) {
 //   * every wave runs the same number of iterations (idle ones compute on clamped rows and store nothing) so the
 //     barriers line up.
 // L2 traffic per 128 rows: one sweep of the layer-3 weights (208 KB) instead of one sweep of both layers per 32 rows.
-template <int C1, int C2, int C3, int NS>
+// SPREAD (hidden-layer layout GP_SA_TAIL_SPREAD, genpose_hip.h): the r = C2 % 16 channels of the last, partly filled 16-channel block
+// sit at positions 4 (c % 4) + c / 4, i.e. in k-steps jj < ceil(r / 4) of all four lane groups, so layer 3 skips the k-steps of
+// that block that only multiply padding (196 channels: one MFMA instead of four, -5.8 % of layer 3).
+template <int C1, int C2, int C3, int NS, bool SPREAD>
 __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int ncentres_total) {
     constexpr int PT = NS / 16, Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16, NWV = 8, NTH = 512;
+    constexpr int TAIL_JJ = (SPREAD && C2 % 16) ? (C2 % 16 + 3) / 4 : 4;  // k-steps of the last k-block that carry channels
     static_assert(Q3 % 4 == 0 && (Q3 * 64) % NTH == 0, "layer-3 slice must split evenly over the workgroup");
     constexpr int SLICE = Q3 * 64;          // f32x4 per k-group slice of layer 3
     constexpr int PER_T = SLICE / NTH;      // f32x4 each thread moves per slice
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
 #pragma unroll
                 for (int u = 0; u < 4; ++u) wn[u] = (n0 + 4 < Q3) ? slot[(n0 + 4 + u) * 64 + lo] : nslot[u * 64 + lo];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
+                for (int jj = 0; jj < (q == Q2 - 1 ? TAIL_JJ : 4); ++jj)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc3[n0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[q][jj], wf[u][jj], acc3[n0 + u], 0, 0, 0);  // transposed
 #pragma unroll
@@ -882,12 +886,12 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
     }
 }
 
-template <int C1, int C2, int C3, int NS>
+template <int C1, int C2, int C3, int NS, bool SPREAD>
 int launch_chain_ring(const SAPreArgs &a, int b, hipStream_t st) {
     constexpr int Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16;
     const size_t lds = ((size_t)(Q1 * Q2 + 3 * Q3) * 64 + C1) * sizeof(f32x4);
     if (lds > 160 * 1024) return GP_EINVAL;
-    auto kern = sa_chain_ring_kernel<C1, C2, C3, NS>;
+    auto kern = sa_chain_ring_kernel<C1, C2, C3, NS, SPREAD>;
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -985,9 +989,10 @@ int gp_point_linear(int rows, int k_in, int n_out, const float *x, const float *
     return gp_launch_status();
 }
 
-int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz, const int32_t *idx,
-                      const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2, const float *bias2,
-                      const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s) {
+int gp_sa_pre_mlp_max_layout(int hidden_layout, int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz,
+                             const int32_t *idx, const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2,
+                             const float *bias2, const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s) {
+    if (hidden_layout != GP_SA_TAIL_PLAIN && hidden_layout != GP_SA_TAIL_SPREAD) return GP_EINVAL;
     if (b < 0 || n <= 0 || np <= 0 || ns <= 0 || c1 <= 0 || c2 <= 0 || c3 <= 0) return GP_EINVAL;
     if (!xyz || !wxyz || !bias1 || !wpack2 || !bias2 || !wpack3 || !bias3 || !out) return GP_EINVAL;
     const bool groupall = !idx && !new_xyz;  // GroupAll level: one neighbourhood = all n points
@@ -999,7 +1004,7 @@ int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, cons
     if (b == 0) return GP_OK;
     SAPreArgs a{n, np, ns, c1, c2, c3, zstride, zoff, xyz, new_xyz, z, idx, wxyz, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off,
                 groupall ? 1 : 0};
-    if (groupall) return launch_pre<32>(a, b, (hipStream_t)s);
+    if (groupall) return launch_pre<32>(a, b, (hipStream_t)s);  // 64-row tiles: slower where they fit (203 vs 167 us at 320 clouds)
     if (!z) {
         if (c1 == 16 && c2 == 16 && c3 == 32 && ns == 16) return launch_chain<16, 16, 32, 16>(a, b, (hipStream_t)s);
         if (c1 == 32 && c2 == 32 && c3 == 64 && ns == 32) return launch_chain<32, 32, 64, 32>(a, b, (hipStream_t)s);
@@ -1007,12 +1012,29 @@ int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, cons
     if (z && (zoff % 4) == 0 && (zstride % 4) == 0) {
         if (c1 == 64 && c2 == 64 && c3 == 128 && ns == 16) return launch_chain_lds<64, 64, 128, 16>(a, b, (hipStream_t)s);
         if (c1 == 64 && c2 == 96 && c3 == 128 && ns == 32) return launch_chain_lds<64, 96, 128, 32>(a, b, (hipStream_t)s);
-        if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 16) return launch_chain_ring<128, 196, 256, 16>(a, b, (hipStream_t)s);
-        if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 32) return launch_chain_ring<128, 196, 256, 32>(a, b, (hipStream_t)s);
+        const bool spread = hidden_layout == GP_SA_TAIL_SPREAD;
+        if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 16)
+            return spread ? launch_chain_ring<128, 196, 256, 16, true>(a, b, (hipStream_t)s) : launch_chain_ring<128, 196, 256, 16, false>(a, b, (hipStream_t)s);
+        if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 32)
+            return spread ? launch_chain_ring<128, 196, 256, 32, true>(a, b, (hipStream_t)s) : launch_chain_ring<128, 196, 256, 32, false>(a, b, (hipStream_t)s);
     }
     const bool narrow = c1 <= 64 && c2 <= 64 && c3 <= 64;
     if (ns <= 32 && !narrow) return launch_pre<32>(a, b, (hipStream_t)s);
     return launch_pre<64>(a, b, (hipStream_t)s);
+}
+
+int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz, const int32_t *idx,
+                      const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2, const float *bias2,
+                      const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s) {
+    return gp_sa_pre_mlp_max_layout(GP_SA_TAIL_PLAIN, b, n, np, ns, c1, c2, c3, xyz, new_xyz, idx, z, zstride, zoff, wxyz, bias1, wpack2, bias2, wpack3,
+                                    bias3, out, cout_total, cout_off, s);
+}
+
+int gp_sa_tail_position(int c2, int channel) {
+    if (c2 <= 0 || channel < 0 || channel >= c2) return GP_EINVAL;
+    const int blk = channel / 16, c = channel % 16;
+    if (c2 % 16 == 0 || blk != c2 / 16) return channel;  // full blocks keep their order
+    return blk * 16 + 4 * (c % 4) + c / 4;
 }
 
 int64_t gp_pack_weight_size(int n_out, int k_in) { return (int64_t)(gp_round16(n_out) / 16) * (gp_round16(k_in) / 16) * 256; }

@@ -334,23 +334,35 @@ __global__ __launch_bounds__(gp_chain::NT, 1) void pc_step_chain_kernel(PcArgs a
             cen[p][0] = cp[0], cen[p][1] = cp[1], cen[p][2] = cp[2];
         }
     }
+    // memory returns in order: what the sampler update needs (row operands above, schedule, the batch's partial sums) is asked for
+    // first, the ring start-up behind it - the update then runs while the weights are still on their way
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int grp = blockIdx.x / a.wgpg;
+    const float *pp = a.partials + (size_t)(i > 0 ? i - 1 : 0) * a.nparts + (size_t)grp * a.ppg;
     if (i > 0) {
         const float *sc = a.sched + (size_t)(i - 1) * 4;
         gdiff = sc[1], dt = sc[2], sqdt = sc[3];
-        const int grp = blockIdx.x / a.wgpg;
         if (a.gn_ext) {
             gn = a.gn_ext[(size_t)(i - 1) * a.ngroups + grp];
-            if (a.gn_rows > 0.f) gn = gn / a.gn_rows;
         } else {
-            float s = 0.f;
-            const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)grp * a.ppg;
-            for (int q = lane; q < a.ppg; q += 64) s += pp[q];
-            gn = wave_sum_f32(s) / (float)a.rows_per_group;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) psum[u] = lane + 64 * u < a.ppg ? pp[lane + 64 * u] : 0.f;
         }
     }
+    gp_chain::Staged<PT> sg;
     if (i < a.nsteps) {
-        gp_chain::begin<PT>(st, lds, net, a.cvec, tvec, wg_row0, a.nrows, a.kcand);
         sigma = a.sched[(size_t)i * 4 + 0];
+        gp_chain::begin_request<PT>(st, sg, net, a.cvec, tvec, wg_row0, a.nrows, a.kcand);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (i > 0) {
+        if (a.gn_ext) {
+            if (a.gn_rows > 0.f) gn = gn / a.gn_rows;
+        } else {
+            float s = ((psum[0] + psum[1]) + psum[2]) + psum[3];  // the order of `for (q = lane; q < ppg; q += 64) s += pp[q]`
+            for (int q = lane + 256; q < a.ppg; q += 64) s += pp[q];
+            gn = wave_sum_f32(s) / (float)a.rows_per_group;
+        }
     }
     f32x4 xf[PT];
     if (i > 0) {
@@ -380,6 +392,8 @@ __global__ __launch_bounds__(gp_chain::NT, 1) void pc_step_chain_kernel(PcArgs a
         }
         if (i == a.nsteps) return;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    gp_chain::begin_deposit<PT>(sg, lds);
 #pragma unroll
     for (int p = 0; p < PT; ++p) xf[p] = gp_chain::pose_fragment(xv[p], g);
     float f[PT][POSE];

@@ -94,23 +94,30 @@ struct State {
     int cloud0;         // first cloud of the workgroup's rows
 };
 
-// Ring prologue (slices 0, 1 -> slots 0, 1; slice 2 -> registers) and the staged epilogue operands (requires Cfg<PT>::fits(kcand):
-// cvec + tvec of every cloud the workgroup's rows touch sit in LDS).  Call AFTER the per-row
-// operand requests have been issued (their latency and this one's then overlap); run() starts with the barrier that publishes
-// these LDS writes.
+// Ring prologue in two halves, so that the caller's own work runs between the request and the first use:
+//   begin_request()  asks for the first W slices, slice W (-> hold) and the staged epilogue operands - w_out (+ a row of zeros: the
+//                    output layers' A operand has four rows of which three are real), the two hidden biases, cvec of every cloud the
+//                    workgroup's rows touch and tvec (requires Cfg<PT>::fits(kcand)).  Issue the per-row operand requests BEFORE it:
+//                    memory returns in order, so whatever the caller needs first must be asked for first;
+//   begin_deposit()  writes them to LDS; run() starts with the barrier that publishes these writes.
 //   wg_row0: first row of the workgroup; row_end: one past the last valid row it may touch (rows beyond are clamped duplicates)
+constexpr int N_WOUT = ((POSE + 1) * HID / 4 + NT - 1) / NT, N_CVT = NCL * (HEADS / 4) / NT;
+static_assert(NCL * (HEADS / 4) % NT == 0 && HID / 4 <= NT, "staging loops");
 template <int PT>
-__device__ __forceinline__ void begin(State<PT> &st, float *lds, const gp_scorenet &net, const float *__restrict__ cvec, const float *__restrict__ tvec,
-                                      int wg_row0, int row_end, int kcand) {
+struct Staged {
+    f32x4 first[Cfg<PT>::W][PER_T];
+    f32x4 wout[N_WOUT], b0, b2, cv[N_CVT], tv[N_CVT];
+};
+template <int PT>
+__device__ __forceinline__ void begin_request(State<PT> &st, Staged<PT> &sg, const gp_scorenet &net, const float *__restrict__ cvec,
+                                              const float *__restrict__ tvec, int wg_row0, int row_end, int kcand) {
     using C = Cfg<PT>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f32x4 *ring = reinterpret_cast<f32x4 *>(lds);
-    f32x4 first[C::W][PER_T];
 #pragma unroll
     for (int t = 0; t < C::W; ++t) {
         const SliceSrc src = slice_src(net, t);
 #pragma unroll
-        for (int u = 0; u < PER_T; ++u) first[t][u] = slice_elem(src, tid + u * NT);
+        for (int u = 0; u < PER_T; ++u) sg.first[t][u] = slice_elem(src, tid + u * NT);
     }
     {
         const SliceSrc src = slice_src(net, C::W);
@@ -124,27 +131,52 @@ __device__ __forceinline__ void begin(State<PT> &st, float *lds, const gp_scoren
         r = r < row_end ? r : row_end - 1;
         st.cloud[p] = r / kcand;
     }
-    // w_out (+ a row of zeros: the output layers run on the matrix pipe as a 16-row operand of which 3 rows are real), the two hidden biases
-    for (int f = tid; f < (POSE + 1) * HID / 4; f += NT)
-        reinterpret_cast<f32x4 *>(lds + C::OFF_WOUT)[f] = f < POSE * HID / 4 ? reinterpret_cast<const f32x4 *>(net.w_out)[f] : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int f = tid; f < HID / 4; f += NT) {
-        reinterpret_cast<f32x4 *>(lds + C::OFF_B0)[f] = reinterpret_cast<const f32x4 *>(net.b_pose0)[f];
-        reinterpret_cast<f32x4 *>(lds + C::OFF_B2)[f] = reinterpret_cast<const f32x4 *>(net.b_pose2)[f];
+#pragma unroll
+    for (int u = 0; u < N_WOUT; ++u) {
+        const int f = tid + u * NT;
+        sg.wout[u] = f < POSE * HID / 4 ? reinterpret_cast<const f32x4 *>(net.w_out)[f] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    {
-        const int last_cloud = (row_end - 1) / kcand;
-        for (int f = tid; f < NCL * (HEADS / 4); f += NT) {
-            const int c = f / (HEADS / 4), o = f - c * (HEADS / 4);
-            int cl = st.cloud0 + c;
-            cl = cl < last_cloud ? cl : last_cloud;
-            reinterpret_cast<f32x4 *>(lds + C::OFF_CVT)[f] =
-                reinterpret_cast<const f32x4 *>(cvec + (size_t)cl * HEADS)[o] + reinterpret_cast<const f32x4 *>(tvec)[o];
-        }
+    if (tid < HID / 4) {
+        sg.b0 = reinterpret_cast<const f32x4 *>(net.b_pose0)[tid];
+        sg.b2 = reinterpret_cast<const f32x4 *>(net.b_pose2)[tid];
     }
+    const int last_cloud = (row_end - 1) / kcand;
+#pragma unroll
+    for (int u = 0; u < N_CVT; ++u) {
+        const int f = tid + u * NT, c = f / (HEADS / 4), o = f - c * (HEADS / 4);
+        int cl = st.cloud0 + c;
+        cl = cl < last_cloud ? cl : last_cloud;
+        sg.cv[u] = reinterpret_cast<const f32x4 *>(cvec + (size_t)cl * HEADS)[o];
+        sg.tv[u] = reinterpret_cast<const f32x4 *>(tvec)[o];
+    }
+}
+template <int PT>
+__device__ __forceinline__ void begin_deposit(const Staged<PT> &sg, float *lds) {
+    using C = Cfg<PT>;
+    const int tid = threadIdx.x;
+    f32x4 *ring = reinterpret_cast<f32x4 *>(lds);
+#pragma unroll
+    for (int u = 0; u < N_WOUT; ++u) {
+        const int f = tid + u * NT;
+        if (f < (POSE + 1) * HID / 4) reinterpret_cast<f32x4 *>(lds + C::OFF_WOUT)[f] = sg.wout[u];
+    }
+    if (tid < HID / 4) {
+        reinterpret_cast<f32x4 *>(lds + C::OFF_B0)[tid] = sg.b0;
+        reinterpret_cast<f32x4 *>(lds + C::OFF_B2)[tid] = sg.b2;
+    }
+#pragma unroll
+    for (int u = 0; u < N_CVT; ++u) reinterpret_cast<f32x4 *>(lds + C::OFF_CVT)[tid + u * NT] = sg.cv[u] + sg.tv[u];
 #pragma unroll
     for (int t = 0; t < C::W; ++t)
 #pragma unroll
-        for (int u = 0; u < PER_T; ++u) ring[t * SLICE + tid + u * NT] = first[t][u];
+        for (int u = 0; u < PER_T; ++u) ring[t * SLICE + tid + u * NT] = sg.first[t][u];
+}
+template <int PT>
+__device__ __forceinline__ void begin(State<PT> &st, float *lds, const gp_scorenet &net, const float *__restrict__ cvec, const float *__restrict__ tvec,
+                                      int wg_row0, int row_end, int kcand) {
+    Staged<PT> sg;
+    begin_request<PT>(st, sg, net, cvec, tvec, wg_row0, row_end, kcand);
+    begin_deposit<PT>(sg, lds);
 }
 
 // End of a ring step.  What the ring needs from this barrier: (i) every wave's reads of the slot it just multiplied have

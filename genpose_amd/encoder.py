@@ -172,7 +172,7 @@ class Pointnet2EncoderHIP:
                 off, zoff = 0, 0
                 for sc in scales:
                     (w1, b1), (w2, b2), (w3, b3) = sc.layers
-                    _lib.call("gp_sa_pre_mlp_max", B, n, 1, n, sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), None, None, ptr(z), zstride,
+                    _lib.call("gp_sa_pre_mlp_max_layout", sc.hidden_layout, B, n, 1, n, sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), None, None, ptr(z), zstride,
                               zoff, ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out), cout_total, off, st)
                     off += sc.couts[2]
                     zoff += sc.couts[0]
@@ -188,7 +188,7 @@ class Pointnet2EncoderHIP:
             off, zoff = 0, 0
             for i, sc in enumerate(scales):
                 (w1, b1), (w2, b2), (w3, b3) = sc.layers
-                _lib.call("gp_sa_pre_mlp_max", B, n, npnt, nss[i], sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(new_xyz),
+                _lib.call("gp_sa_pre_mlp_max_layout", sc.hidden_layout, B, n, npnt, nss[i], sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(new_xyz),
                           ptr(src["bq"][k][i]), ptr(z), zstride, zoff, ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out),
                           cout_total, off, st)
                 off += sc.couts[2]

@@ -58,6 +58,8 @@ class SAScale:
         self.cin = cin_feat
         self.layers = []
         self.couts = []
+        self.hidden_layout = 0  # GP_SA_TAIL_PLAIN
+        folded = []
         l = 0
         while f"{prefix}layer{l}.conv.weight" in sd:
             p = f"{prefix}layer{l}."
@@ -77,11 +79,25 @@ class SAScale:
                 wxyz[: Wf.shape[0], :3] = Wf[:, :3].float()
                 self.wxyz = wxyz.to(device)
                 Wf = torch.cat([Wf[:, 3:], Wf[:, :3]], dim=1)  # [dx,dy,dz,feat] -> [feat,dx,dy,dz]
-            self.layers.append((pack_weight(Wf.float()).to(device), pad_bias(bf.float()).to(device)))
+            folded.append((Wf.float(), bf.float()))
             self.couts.append(Wf.shape[0])
             l += 1
         if l != 3:
             raise ValueError(f"{prefix}: the fused SA kernel expects 3-layer shared MLPs, found {l}")
+        c2 = self.couts[1]
+        if c2 % 16:
+            # hidden width not a multiple of 16 (light level 2: 196): the channels of the last, partly filled 16-channel block go to
+            # positions 4 (c % 4) + c / 4 of it (GP_SA_TAIL_SPREAD, genpose_hip.h) - as rows of layer 2 and columns of layer 3 alike, so
+            # the network is unchanged - and the chain kernels skip the k-steps of that block that only multiply padding
+            self.hidden_layout = 1
+            pos = torch.tensor([_lib.lib().gp_sa_tail_position(c2, c) for c in range(c2)], dtype=torch.long)
+            (W2, b2), (W3, b3) = folded[1], folded[2]
+            W2s, b2s = torch.zeros(_round16(c2), W2.shape[1]), torch.zeros(_round16(c2))
+            W2s[pos], b2s[pos] = W2, b2
+            W3s = torch.zeros(W3.shape[0], _round16(c2))
+            W3s[:, pos] = W3
+            folded[1], folded[2] = (W2s, b2s), (W3s, b3)
+        self.layers = [(pack_weight(W).to(device), pad_bias(b).to(device)) for W, b in folded]
 
 
 class EncoderWeights:

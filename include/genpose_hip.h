@@ -124,6 +124,18 @@ int gp_point_linear(int rows, int k_in, int n_out, const float *x, const float *
 int gp_sa_pre_mlp_max(int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz, const int32_t *idx,
                       const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2, const float *bias2,
                       const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s);
+/* The same with a choice of HIDDEN-LAYER LAYOUT for widths c2 that are not a multiple of 16 (light encoder level 2: 196 = 12 x 16 + 4).
+ * GP_SA_TAIL_PLAIN: channel c of the hidden layer is row c of wpack2 / bias2 and column c of wpack3 (what gp_sa_pre_mlp_max assumes).
+ * GP_SA_TAIL_SPREAD: the r = c2 % 16 channels of the last, partly filled 16-channel block are moved to positions
+ * 4 (c % 4) + c / 4 of that block (gp_sa_tail_position(c2, channel) gives the padded index; the caller packs a [round16(c2), c1]
+ * layer-2 matrix / bias and a [c3, round16(c2)] layer-3 matrix with the channels there and zeros elsewhere).  The network is the same
+ * function; the register-chain kernels then skip the MFMAs of the last block that only multiply padding (196: one k-step of four). */
+#define GP_SA_TAIL_PLAIN 0
+#define GP_SA_TAIL_SPREAD 1
+int gp_sa_pre_mlp_max_layout(int hidden_layout, int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz,
+                             const int32_t *idx, const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const float *wpack2,
+                             const float *bias2, const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s);
+int gp_sa_tail_position(int c2, int channel);
 
 /* Weight packing for the MFMA layers (host-callable helpers operating on HOST memory):
  * W is [n_out, k_in] row-major (torch Linear / 1x1 conv layout).  Packed size in floats = gp_pack_weight_size(). */

@@ -53,10 +53,19 @@ def test_sa_scale_paths_agree(level, scale):
         _lib.call("gp_point_linear", B * n, cin, zstride, ptr(f_d), ptr(ew.z_weights[level]), ptr(z), st)
     _lib.call("gp_sa_pre_mlp_max", B, n, npnt, ns, spec[0], spec[1], spec[2], ptr(xyz_d), ptr(nx_d), ptr(bq_d), ptr(z), zstride, zoff,
               ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out_b), cout_all, off, st)
+    # ... and as the encoder calls it: with the hidden-layer layout the weights were packed for (level 2, 196 channels: the chain
+    # kernels then skip the k-steps of the last 16-channel block that only hold padding)
+    out_c = torch.zeros(B, npnt, cout_all, device="cuda")
+    _lib.call("gp_sa_pre_mlp_max_layout", sc.hidden_layout, B, n, npnt, ns, spec[0], spec[1], spec[2], ptr(xyz_d), ptr(nx_d), ptr(bq_d), ptr(z),
+              zstride, zoff, ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out_c), cout_all, off, st)
+    assert sc.hidden_layout == (1 if spec[1] % 16 else 0)
     a = out_a[:, :, off:off + spec[-1]].cpu().numpy()
     b = out_b[:, :, off:off + spec[-1]].cpu().numpy()
+    c = out_c[:, :, off:off + spec[-1]].cpu().numpy()
     np.testing.assert_allclose(a, ref, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(b, ref, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(c, ref, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(c, b, rtol=0, atol=2e-6 * np.abs(b).max())
     assert np.all(out_a[:, :, :off].cpu().numpy() == 0) and np.all(out_b[:, :, off + spec[-1]:].cpu().numpy() == 0)  # writes only its slice
 
 
