@@ -319,9 +319,9 @@ constexpr size_t trunk_lds_bytes() {
 //     rows     3200   6400  12800  16000  32000  64000
 //     16       26.1   50.8   96.8   95.0  180.5  346
 //     32       39.7   39.7   75.0   74.8  146.6  290
-//     128     140.2  140.9  142.7  141.7  141.9  283
-// i.e. a ROUND of <= 256 workgroups costs 24.5 / 37.5 / 141.5 us; the plan with the smallest predicted launch time is taken.
-constexpr float TILE16_ROUND_US = 24.5f, TILE32_ROUND_US = 37.5f, CHAIN128_ROUND_US = 141.5f;
+//     128     137.2  137.9  139.4  138.6  138.6  278
+// i.e. a ROUND of <= 256 workgroups costs 24.5 / 37.5 / 138.6 us; the plan with the smallest predicted launch time is taken.
+constexpr float TILE16_ROUND_US = 24.5f, TILE32_ROUND_US = 37.5f, CHAIN128_ROUND_US = 138.6f;
 static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
     // a workgroup never straddles two batches; the chain form stages cvec + tvec of <= 4 clouds per workgroup (trunk_chain.h: NCL)
     auto fits = [&](int rows) {
