@@ -54,8 +54,8 @@ FLOP_ENCODER_EXECUTED = encoder_flops_executed()  # 1.69e9
 FLOP_CLOUD_EMBED = 1.573e6
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # Request batching of the default run: consecutive 64-cloud batches that share one encoder pass and one sampler launch chain (each keeps
-# its own batch-global coupling and gets its stand-alone result).  Measured on MI355X: 1 -> 16.5 k, 5 -> 24.1 k, 10 -> 25.0 k, 20 -> 25.4 k
-# poses/s (32 000 rows = 1000 32-row tiles = 3.9 rounds of the 256 CUs; the encoder's persistent kernels amortise over 640 clouds).
+# its own batch-global coupling and gets its stand-alone result).  Measured on MI355X: 1 -> 17.0 k, 5 -> 24.9 k, 10 -> 26.4 k, 20 -> 27.0 k
+# poses/s (32 000 rows = 250 128-row workgroups of the chain-form sampler, one per CU; the encoder's persistent kernels amortise over 640 clouds).
 DEFAULT_BATCHES_PER_LAUNCH = 10
 
 
