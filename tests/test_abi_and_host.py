@@ -96,6 +96,63 @@ def test_bn_folding_equals_conv_bn():
     assert ew.out_dim == 1024 and [s.couts for s in ew.levels[2]] == [[128, 196, 256], [128, 196, 256]]
 
 
+def test_spread_layout_of_a_partly_filled_hidden_block_is_the_same_network():
+    """GP_SA_TAIL_SPREAD (genpose_hip.h): the channels of the last, partly filled 16-channel block of a hidden layer move to positions
+    4 (c % 4) + c / 4 of that block, as rows of layer 2 and columns of layer 3 alike.  Host side only: the position map, and that the
+    packed streams of the light encoder's 196-wide level multiply out to the plain layers (unpacked with the documented A-fragment
+    layout, gp_common.h) - so any kernel that multiplies every position computes the same function."""
+    from genpose_amd import _lib
+    from genpose_amd.weights import EncoderWeights
+    pos = [_lib.lib().gp_sa_tail_position(196, c) for c in range(196)]
+    assert pos[:192] == list(range(192)) and pos[192:] == [192, 196, 200, 204]
+    assert [_lib.lib().gp_sa_tail_position(40, c) for c in range(32, 40)] == [32, 36, 40, 44, 33, 37, 41, 45]
+    assert [_lib.lib().gp_sa_tail_position(64, c) for c in (0, 47, 63)] == [0, 47, 63]  # full blocks keep their order
+    assert _lib.lib().gp_sa_tail_position(196, 196) < 0 and _lib.lib().gp_sa_tail_position(0, 0) < 0
+    sd = go.make_state_dict(0, "score")
+    sc = EncoderWeights(sd, "cpu").levels[2][1]
+    assert sc.hidden_layout == 1 and EncoderWeights(sd, "cpu").levels[1][0].hidden_layout == 0
+
+    def unpack(p, n_pad, k_pad):  # [kg][nc][lane][jj] -> W[n][k]
+        p = p.reshape(k_pad // 16, n_pad // 16, 64, 4)
+        W = torch.zeros(n_pad, k_pad)
+        for lane in range(64):
+            for jj in range(4):
+                W[(lane & 15)::16, (4 * (lane >> 4) + jj)::16] = p[:, :, lane, jj].T
+        return W
+
+    prefix = "pts_encoder.SA_modules.2.mlps.1."
+    fold = []
+    for l in range(3):
+        q = f"{prefix}layer{l}."
+        W = sd[q + "conv.weight"].double().reshape(sd[q + "conv.weight"].shape[0], -1)
+        scale = sd[q + "bn.bn.weight"].double() / torch.sqrt(sd[q + "bn.bn.running_var"].double() + 1e-5)
+        fold.append(((W * scale[:, None]).float(), (sd[q + "bn.bn.bias"].double() - sd[q + "bn.bn.running_mean"].double() * scale).float()))
+    (w2p, b2p), (w3p, _) = sc.layers[1], sc.layers[2]
+    W2s, W3s = unpack(w2p, 208, 128), unpack(w3p, 256, 208)
+    h1 = torch.randn(37, 128).abs()
+    plain = torch.relu(h1 @ fold[1][0].T + fold[1][1]) @ fold[2][0].T
+    spread = torch.relu(h1 @ W2s.T + b2p) @ W3s.T
+    np.testing.assert_allclose(spread.numpy(), plain.numpy(), rtol=1e-5, atol=1e-5)
+    live = torch.zeros(208, dtype=torch.bool)
+    live[pos] = True
+    assert W2s[~live].abs().max() == 0 and W3s[:, ~live].abs().max() == 0 and b2p[~live].abs().max() == 0
+
+
+def test_launch_plans_are_consistent():
+    """Host side of the launch plans: the RK45 stage kernels take the sampler's plan (16 / 32-row tiles, 128-row chain form for large
+    score-model launches); the forward + backward models stay on 16-row tiles; groups whose rows do not split are refused."""
+    import ctypes
+    from genpose_amd import _lib
+    L = _lib.lib()
+    assert L.gp_rk45_plan_rows(0, 1, 64, 50) == 16 and L.gp_rk45_plan_rows(0, 10, 64, 50) == 128
+    assert L.gp_rk45_plan_rows(1, 10, 64, 50) == 16 and L.gp_rk45_plan_rows(2, 10, 64, 50) == 16
+    assert L.gp_rk45_plan_rows(0, 10, 64, 10) in (16, 32)  # k < 43: a 128-row workgroup would span more clouds than it stages
+    assert L.gp_rk45_plan_rows(0, 0, 64, 50) < 0 and L.gp_rk45_plan_rows(3, 1, 64, 50) < 0
+    t, n = ctypes.c_int(0), ctypes.c_int(0)
+    assert L.gp_pc_layout(0, 0, 10, 64, 50, ctypes.byref(t), ctypes.byref(n)) == 0 and t.value == L.gp_rk45_plan_rows(0, 10, 64, 50)
+    assert L.gp_pc_layout(0, 128, 2, 3, 50, ctypes.byref(t), ctypes.byref(n)) != 0  # 150 rows per batch: a workgroup would straddle two
+
+
 def test_scorenet_weight_block_shapes():
     from genpose_amd.weights import ScoreNetWeights
     w = ScoreNetWeights(go.make_state_dict(0, "energy"), "cpu")
