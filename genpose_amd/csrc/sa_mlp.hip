@@ -869,7 +869,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
                 for (int u = 0; u < 4; ++u) wpre[u] = wn[u];
             }
             ++gstep;
-            __syncthreads();
+            __syncthreads();  // (the fence-free s_barrier of trunk_chain.h measured equal here: two waves per SIMD cover the fence)
         }
         {
             const int c = wave_global + (it / PT) * nwaves;
