@@ -114,6 +114,39 @@ def test_config1_as_timed():
     _assert_pc100_close(got5[i].cpu().numpy(), ref.numpy(), f"configs[1] batch {i} (3200 rows x 100 steps) vs oracle")
 
 
+def test_ode_100_as_timed():
+    """The secondary mode of the bench line (`ode_100`: cond_ode_sampler(sampling_steps=100), T0 = 0.55) exactly as bench.py times it:
+    GroupedODEPredictor with the bench's request batching (10 x 64 clouds = 32 000 rows per launch: the RK45 stage kernels run in the
+    chain form of the trunk, every batch with its own step controller), injected prior draws.  Every batch: finite, unit and orthogonal
+    rotation columns; a second solve gives the same bits; and request batching does not change a batch's solve - against one batch per
+    launch (16-row tile form) the same evaluation count, poses within the ODE tolerance of the small tests (rotation block 2e-3
+    absolute, translations 5e-4 of their scale)."""
+    import bench
+    from genpose_amd import synth
+    from genpose_amd.pipeline import GroupedODEPredictor
+    B1, K, G, T0 = 64, 50, bench.DEFAULT_BATCHES_PER_LAUNCH, 0.55
+    agent = make_agent("score", "ode", 100)
+    batches = [torch.from_numpy(synth.make_batch(B1, start=7000 + B1 * i)).cuda() for i in range(G)]
+    gen = torch.Generator().manual_seed(77)
+    priors = [torch.randn(B1 * K, 9, generator=gen).cuda() for _ in range(G)]
+    pg = GroupedODEPredictor(agent, B1, K, T0=T0, batches_per_launch=G)
+    got = [g.clone() for g in pg.run(batches, prior_noise=priors)]
+    nfev = list(pg.last_nfev)
+    assert pg._sampler(G).tile in (32, 128) and len(nfev) == G and all(150 < v < 400 for v in nfev), nfev
+    for g in got:
+        assert g.shape == (B1, K, 9) and g.dtype == torch.float64
+        _check_pose_properties(g.float())
+    again = pg.run(batches, prior_noise=priors)
+    for a, b in zip(again, got):
+        assert torch.equal(a, b)
+    p1 = GroupedODEPredictor(agent, B1, K, T0=T0, batches_per_launch=1)
+    one = [g.clone() for g in p1.run(batches, prior_noise=priors)]
+    assert p1._sampler(1).tile == 16 and list(p1.last_nfev) == nfev, (p1.last_nfev, nfev)
+    a, b = torch.stack(got).cpu().numpy(), torch.stack(one).cpu().numpy()
+    np.testing.assert_allclose(a[..., :6], b[..., :6], rtol=0, atol=2e-3, err_msg="rotation block, 10 per launch vs 1 per launch")
+    np.testing.assert_allclose(a[..., 6:], b[..., 6:], rtol=0, atol=5e-4 * np.abs(b[..., 6:]).max(), err_msg="translations")
+
+
 @pytest.mark.parametrize("B", [64, 320])
 def test_encoder_vs_oracle_at_bench_sizes(B):
     """The encoder at the batch sizes bench.py runs it at (64 = one batch, 320 = five batches per launch).  Clouds are independent,
