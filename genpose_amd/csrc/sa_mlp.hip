@@ -886,6 +886,212 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupAll level (128 points x [256 hoisted + xyz] -> C2 -> 512 per cloud and scale) as a register chain with BOTH weight matrices through
+// an LDS ring: one 8-wave workgroup owns one CLOUD at a time (8 waves x 16 rows = its 128 points), so that
+//   * a pass over the weights (0.77 / 1.15 MB) serves 128 rows instead of the 32 of the tile kernel, which is bound by that stream;
+//   * the pooling over the cloud needs no atomics: a wave pools its 16 rows in registers (last layer transposed, lane = channel), the
+//     eight waves meet in LDS once per cloud.
+// Ring: three slots, one 16-wide k-block of a layer per step (layer 2: Q2 fragments; layer 3: 16 of its 32 output chunks, two halves
+// of Q2 steps each, which keeps the accumulators at 64 registers), one barrier per step, the slice two steps ahead held in registers -
+// the scheme of sa_chain_ring_kernel; the stream runs on from cloud to cloud.  Two waves per SIMD, compiler-scheduled: one wave's
+// VALU work (layer 1, bias + ReLU, pooling) runs under the other's MFMAs (profiles/r3_sa_ring32_experiment.txt).
+template <int C1, int C2, int C3>
+__global__ __launch_bounds__(512) void sa_groupall_ring_kernel(SAPreArgs a, int nclouds) {
+    constexpr int Q1 = C1 / 16, Q2 = C2 / 16, Q3 = C3 / 16, NWV = 8, NTH = 512;
+    static_assert(C1 % 16 == 0 && C2 % 16 == 0 && Q3 == 32 && Q2 % 4 == 0, "light encoder's GroupAll shapes");
+    constexpr int SLOTF = Q2 > 16 ? Q2 : 16;     // fragments per ring slot
+    constexpr int SLOT = SLOTF * 64;             // f32x4 per slot
+    constexpr int PER_T = (SLOT + NTH - 1) / NTH;
+    constexpr int NSL = Q1 + 2 * Q2;             // slices per cloud: layer 2 k-blocks, then layer 3 (half 0, half 1) k-blocks
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NRS = 4;                                 // ring slots
+    f32x4 *ring = reinterpret_cast<f32x4 *>(lds);          // [NRS][SLOT]
+    f32x4 *w1l = ring + NRS * SLOT;                        // [C1] rows (wx, wy, wz, b1)
+    float *pool = reinterpret_cast<float *>(w1l + C1);     // [NWV][C3] per-wave maxima of the pre-bias layer-3 output
+    float *b2l = pool + NWV * C3;                          // [C2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pt = lane & 15;
+    const f32x4 *w2g = reinterpret_cast<const f32x4 *>(a.w2), *w3g = reinterpret_cast<const f32x4 *>(a.w3);
+    // slice si of the per-cloud stream: base pointer and fragment count
+    auto slice = [&](int si, int &nfrag) -> const f32x4 * {
+        si %= NSL;
+        if (si < Q1) {
+            nfrag = Q2;
+            return w2g + (size_t)si * Q2 * 64;
+        }
+        const int t = si - Q1, half = t / Q2, kb = t - half * Q2;
+        nfrag = 16;
+        return w3g + ((size_t)kb * Q3 + half * 16) * 64;
+    };
+    // a slice is requested into registers in step g and written to its slot in step g + 2 (two register sets): its L2 latency has two
+    // steps (~2 us) to pass before anything waits for it
+    f32x4 hold[2][PER_T];
+    auto request = [&](int set, int si) {
+        int nf;
+        const f32x4 *src = slice(si, nf);
+#pragma unroll
+        for (int u = 0; u < PER_T; ++u) {
+            const int e = tid + u * NTH;
+            hold[set][u] = src[e < nf * 64 ? e : nf * 64 - 1];
+        }
+    };
+    auto deposit = [&](int set, int slot) {
+#pragma unroll
+        for (int u = 0; u < PER_T; ++u) {
+            const int e = tid + u * NTH;
+            if (e < SLOT) ring[slot * SLOT + e] = hold[set][u];
+        }
+    };
+    for (int e = tid; e < C1; e += NTH) {
+        f32x4 w = *reinterpret_cast<const f32x4 *>(a.wxyz + e * 4);
+        w.w = a.b1[e];
+        w1l[e] = w;
+    }
+    for (int e = tid; e < C2; e += NTH) b2l[e] = a.b2[e];
+    const float bias3 = a.b3[tid];
+    request(0, 0);
+    deposit(0, 0);
+    request(0, 1);
+    deposit(0, 1);
+    request(0, 2);  // slices 2 and 3 travel in the two register sets: deposited in steps 0 and 1
+    request(1, 3);
+    __syncthreads();
+    int gstep = 0;  // global ring step: slice gstep % NSL sits in slot gstep % NRS; slices gstep + 2, gstep + 3 are in `hold`
+    f32x4 wpre[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wpre[u] = ring[u * 64 + lane];
+    // one ring step over `NF` fragments (chunks n = 0 .. NF-1 of this slice), the fragments requested one group of four ahead and the first
+    // group of the next step before the barrier
+    // (the register set must be a compile-time index: every step is written for an even and an odd gstep)
+    auto step_begin = [&](auto par) {
+        constexpr int set = decltype(par)::value;
+        deposit(set, (gstep + 2) % NRS);  // slice gstep + 2 (requested two steps ago) -> its slot, last read in step gstep - 2
+        request(set, gstep + 4);
+    };
+#pragma unroll 1
+    for (int cloud = blockIdx.x; cloud < nclouds; cloud += gridDim.x) {
+        // the per-channel operands in LDS do not change from cloud to cloud: an opaque lane group keeps their reads INSIDE the loop
+        // (hoisted out of it they are 90 registers that spill)
+        int g = lane >> 4;
+        asm volatile("" : "+v"(g));
+        // ---- layer 1 (hoisted) is computed k-block by k-block inside layer 2's steps (sixteen fragments held at once, beside the
+        // accumulators, spill): row = point 16 wave + pt of the cloud, absolute coordinates (GroupAll: no centring); its z values are
+        // requested two steps ahead
+        const int row = wave * 16 + pt;
+        const float *xyzp = a.xyz + ((size_t)cloud * a.n + row) * 3;
+        const float dx = xyzp[0], dy = xyzp[1], dz = xyzp[2];
+        const float *zb = a.z + ((size_t)cloud * a.n + row) * a.zstride + a.zoff + 4 * g;
+        f32x4 zq[4];
+        zq[0] = *reinterpret_cast<const f32x4 *>(zb);
+        zq[1] = *reinterpret_cast<const f32x4 *>(zb + 16);
+        zq[2] = *reinterpret_cast<const f32x4 *>(zb + 32);
+        auto layer1 = [&](int q) {
+            const f32x4 r0 = w1l[16 * q + 4 * g + 0], r1 = w1l[16 * q + 4 * g + 1], r2 = w1l[16 * q + 4 * g + 2], r3 = w1l[16 * q + 4 * g + 3];
+            f32x4 v = zq[q % 4];
+            v.x += (r0.x * dx + r0.y * dy + r0.z * dz) + r0.w;
+            v.y += (r1.x * dx + r1.y * dy + r1.z * dz) + r1.w;
+            v.z += (r2.x * dx + r2.y * dy + r2.z * dz) + r2.w;
+            v.w += (r3.x * dx + r3.y * dy + r3.z * dz) + r3.w;
+            return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+        };
+        f32x4 h1q = layer1(0);  // k-block q + 1 is prepared while k-block q is multiplied
+        // ---- layer 2: Q1 ring steps, all Q2 output chunks accumulate across them
+        f32x4 h2[Q2];
+#pragma unroll
+        for (int n = 0; n < Q2; ++n) h2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < Q1; ++q) {
+            if (q & 1) step_begin(std::integral_constant<int, 1>{}); else step_begin(std::integral_constant<int, 0>{});
+            if (q + 3 < Q1) zq[(q + 3) % 4] = *reinterpret_cast<const f32x4 *>(zb + 16 * (q + 3));
+            const f32x4 h1n = q + 1 < Q1 ? layer1(q + 1) : h1q;
+            const f32x4 *slot = ring + (gstep % NRS) * SLOT, *nslot = ring + ((gstep + 1) % NRS) * SLOT;
+#pragma unroll
+            for (int n0 = 0; n0 < Q2; n0 += 4) {
+                f32x4 wf[4], wn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wf[u] = wpre[u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wn[u] = (n0 + 4 < Q2) ? slot[(n0 + 4 + u) * 64 + lane] : nslot[u * 64 + lane];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) h2[n0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][jj], h1q[jj], h2[n0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wpre[u] = wn[u];
+                __builtin_amdgcn_sched_barrier(0);  // one fragment group ahead, not the whole slice (its reads would take 64-96 registers)
+            }
+            h1q = h1n;
+            ++gstep;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int n = 0; n < Q2; ++n) {
+            const f32x4 v = h2[n] + *reinterpret_cast<const f32x4 *>(b2l + 16 * n + 4 * g);
+            h2[n] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+        }
+        // ---- layer 3, transposed (lane = channel 16 n + pt, registers x lane groups = the wave's 16 rows), 16 output chunks at a time
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            f32x4 acc3[16];
+#pragma unroll
+            for (int n = 0; n < 16; ++n) acc3[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) {
+                if (q & 1) step_begin(std::integral_constant<int, 1>{}); else step_begin(std::integral_constant<int, 0>{});
+                const f32x4 *slot = ring + (gstep % NRS) * SLOT, *nslot = ring + ((gstep + 1) % NRS) * SLOT;
+#pragma unroll
+                for (int n0 = 0; n0 < 16; n0 += 4) {
+                    f32x4 wf[4], wn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wf[u] = wpre[u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wn[u] = (n0 + 4 < 16) ? slot[(n0 + 4 + u) * 64 + lane] : nslot[u * 64 + lane];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc3[n0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h2[q][jj], wf[u][jj], acc3[n0 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wpre[u] = wn[u];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ++gstep;
+                __syncthreads();
+            }
+            // the wave's maxima over its 16 rows; the pool buffer was read (previous cloud) many barriers ago
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const float m = points16_max_t(acc3[n]);
+                if (lane < 16) pool[wave * C3 + half * 256 + 16 * n + pt] = m;
+            }
+        }
+        __syncthreads();
+        // max over the eight waves, then bias and ReLU once per channel (max_i relu(x_i + b) = relu(max_i x_i + b))
+        {
+            float m = pool[tid];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) m = fmaxf(m, pool[w * C3 + tid]);
+            a.out[(size_t)cloud * a.cout_total + a.cout_off + tid] = fmaxf(m + bias3, 0.f);
+        }
+        // (the next write to `pool` is a whole layer away: no barrier needed here)
+    }
+}
+
+template <int C1, int C2, int C3>
+int launch_groupall_ring(const SAPreArgs &a, int b, hipStream_t st) {
+    constexpr int Q2 = C2 / 16, SLOTF = Q2 > 16 ? Q2 : 16;
+    const size_t lds = ((size_t)4 * SLOTF * 64 + C1) * sizeof(f32x4) + (size_t)(8 * C3 + C2) * sizeof(float);
+    auto kern = sa_groupall_ring_kernel<C1, C2, C3>;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GP_ELAUNCH;
+        done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(b < 256 ? b : 256), dim3(512), lds, st, a, b);
+    return gp_launch_status();
+}
+
 template <int C1, int C2, int C3, int NS, bool SPREAD>
 int launch_chain_ring(const SAPreArgs &a, int b, hipStream_t st) {
     constexpr int Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16;
@@ -1004,7 +1210,25 @@ int gp_sa_pre_mlp_max_layout(int hidden_layout, int b, int n, int np, int ns, in
     if (b == 0) return GP_OK;
     SAPreArgs a{n, np, ns, c1, c2, c3, zstride, zoff, xyz, new_xyz, z, idx, wxyz, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off,
                 groupall ? 1 : 0};
-    if (groupall) return launch_pre<32>(a, b, (hipStream_t)s);  // 64-row tiles: slower where they fit (203 vs 167 us at 320 clouds)
+    if (groupall) {
+        // The light encoder's GroupAll shapes: whole clouds on the ring kernel (one cloud per 8-wave workgroup, 82 / 123 us of MFMA time
+        // each at the CU's peak - far too coarse to balance a partial round), i.e. full rounds of 256 clouds, or a last round that fills
+        // at least three quarters of the chip; the remaining clouds on 32-row tiles (four per cloud, atomic max into the zeroed output).
+        // At 320 clouds: 256 + 64 -> 102 + 33 us and 150 + 52 us against 167 and 261 us for tiles alone.
+        int nring = 0;
+        if (z && n == 128 && c1 == 256 && c3 == 512 && (c2 == 256 || c2 == 384)) {
+            const int full = (b / 256) * 256;
+            nring = b - full >= 192 ? b : full;
+        }
+        if (nring > 0) {
+            const int rc = c2 == 256 ? launch_groupall_ring<256, 256, 512>(a, nring, (hipStream_t)s) : launch_groupall_ring<256, 384, 512>(a, nring, (hipStream_t)s);
+            if (rc != GP_OK || nring == b) return rc;
+            a.xyz += (size_t)nring * n * 3;
+            a.z += (size_t)nring * n * zstride;
+            a.out += (size_t)nring * cout_total;
+        }
+        return launch_pre<32>(a, b - nring, (hipStream_t)s);  // 64-row tiles: slower where they fit (203 vs 167 us at 320 clouds)
+    }
     if (!z) {
         if (c1 == 16 && c2 == 16 && c3 == 32 && ns == 16) return launch_chain<16, 16, 32, 16>(a, b, (hipStream_t)s);
         if (c1 == 32 && c2 == 32 && c3 == 64 && ns == 32) return launch_chain<32, 32, 64, 32>(a, b, (hipStream_t)s);

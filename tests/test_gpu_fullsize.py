@@ -147,10 +147,12 @@ def test_ode_100_as_timed():
     np.testing.assert_allclose(a[..., 6:], b[..., 6:], rtol=0, atol=5e-4 * np.abs(b[..., 6:]).max(), err_msg="translations")
 
 
-@pytest.mark.parametrize("B", [64, 320])
+@pytest.mark.parametrize("B", [64, 320, 448])
 def test_encoder_vs_oracle_at_bench_sizes(B):
-    """The encoder at the batch sizes bench.py runs it at (64 = one batch, 320 = five batches per launch).  Clouds are independent,
-    so the oracle walks the batch in slices (its grouped tensors are 12 MB per cloud)."""
+    """The encoder at the batch sizes bench.py runs it at (64 = one batch, 320 = five batches per launch) and at 448 clouds.  Clouds are
+    independent, so the oracle walks the batch in slices (its grouped tensors are 12 MB per cloud).  The GroupAll level takes whole
+    rounds of 256 clouds on its ring kernel (one cloud per workgroup) and the rest on 32-row tiles: 64 = tiles only, 320 = 256 + 64,
+    448 = two rounds of the ring kernel, the second three quarters full."""
     from genpose_amd import synth
     from genpose_amd.encoder import Pointnet2EncoderHIP
     sd = go.make_state_dict(0, "score")
