@@ -312,9 +312,9 @@ class ODESampler:
         # read; a solve that needs more continues in chunks of `poll` attempts.
         hist_key = (gname, round(float(T0), 3))
         expect = self._attempt_hist.get(hist_key)
-        # (short solves - tracking: 6-8 attempts - get a graph of exactly one spare attempt: every attempt launched on a finished solve
-        # is seven kernels that exit at once, ~35 us, and a coarse chunk list made 12 attempts out of 7)
-        first = self.poll if expect is None else (expect + 1 if expect < 16 else next((c for c in self.CHUNKS if c >= expect + 2), self.CHUNKS[-1]))
+        # (solves of up to 64 attempts - tracking: 6-8, the benched ODE-100: 36 - get a graph of exactly one spare attempt: every attempt
+        # launched on a finished solve is eight kernels that exit at once, ~35 us, and a coarse chunk list made 12 attempts out of 7)
+        first = self.poll if expect is None else (expect + 1 if expect < 64 else next((c for c in self.CHUNKS if c >= expect + 2), self.CHUNKS[-1]))
         while True:
             chunk = first if n_done == 0 else self.poll
             if self.use_graph:
