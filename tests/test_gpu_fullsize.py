@@ -119,7 +119,7 @@ def test_ode_100_as_timed():
     GroupedODEPredictor with the bench's request batching (10 x 64 clouds = 32 000 rows per launch: the RK45 stage kernels run in the
     chain form of the trunk, every batch with its own step controller), injected prior draws.  Every batch: finite, unit and orthogonal
     rotation columns; a second solve gives the same bits; and request batching does not change a batch's solve - against one batch per
-    launch (16-row tile form) the same evaluation count, poses within the ODE tolerance of the small tests (rotation block 2e-3
+    launch (16-row tile form) the same evaluation count (one attempt of slack), poses within the ODE tolerance of the small tests (rotation block 2e-3
     absolute, translations 5e-4 of their scale)."""
     import bench
     from genpose_amd import synth
@@ -141,7 +141,9 @@ def test_ode_100_as_timed():
         assert torch.equal(a, b)
     p1 = GroupedODEPredictor(agent, B1, K, T0=T0, batches_per_launch=1)
     one = [g.clone() for g in p1.run(batches, prior_noise=priors)]
-    assert p1._sampler(1).tile == 16 and list(p1.last_nfev) == nfev, (p1.last_nfev, nfev)
+    # same controller decisions; an error norm within round-off of 1.0 may flip ONE accept / reject between the two forms of the trunk
+    # (2e-7 apart): at most one attempt (6 evaluations) of difference per batch is tolerated, the poses are held to the tolerance either way
+    assert p1._sampler(1).tile == 16 and all(abs(a_ - b_) <= 6 for a_, b_ in zip(p1.last_nfev, nfev)), (p1.last_nfev, nfev)
     a, b = torch.stack(got).cpu().numpy(), torch.stack(one).cpu().numpy()
     np.testing.assert_allclose(a[..., :6], b[..., :6], rtol=0, atol=2e-3, err_msg="rotation block, 10 per launch vs 1 per launch")
     np.testing.assert_allclose(a[..., 6:], b[..., 6:], rtol=0, atol=5e-4 * np.abs(b[..., 6:]).max(), err_msg="translations")
