@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GENPOSE_HIP_LIB: tuning only (e.g. the GP_TIMING build kept beside the shipped one)
+# GENPOSE_HIP_LIB: tuning only (a variant built with GP_BUILD_TAG=<tag> beside the shipped library, genpose_amd/build.py)
 SO_PATH = os.environ.get("GENPOSE_HIP_LIB") or os.path.join(_HERE, "lib", "libgenpose_hip.so")
 
 c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64

@@ -4,8 +4,10 @@ forward(pts [B,N,3] f32 on the GPU) -> [B,1024].  Launch sequence per call (all 
   1 x gp_fps_chain      FPS + gather for every level (one workgroup per cloud)
   L x gp_ball_query_msg both radii of a level in one pass
   L x gp_point_linear   hoisted feature half of the first layer, once per source point (both scales)
-  2L x gp_sa_pre_mlp_max gather -> xyz half of layer 1 -> layers 2-3 on fp32 MFMA -> max-pool, per scale
-  1 + 2 x the same pair  GroupAll level (tiles of a cloud combine by integer atomic max into a zeroed buffer)
+  2L x gp_sa_pre_mlp_max_layout  gather -> xyz half of layer 1 -> layers 2-3 on fp32 MFMA -> max-pool, per scale (register-chain kernels;
+                        the hidden-layer layout the weights were packed for, weights.SAScale)
+  1 + 2 x the same pair  GroupAll level: whole rounds of 256 clouds on the ring kernel (one cloud per workgroup), the rest on 32-row tiles
+                        (the tiles of a cloud combine by integer atomic max into a zeroed buffer)
 Intermediate features stay point-major [B, n, C]; the reference's grouped [B,C+3,np,ns] tensors never exist.
 """
 import ctypes
