@@ -7,6 +7,17 @@
 
 static inline int gp_launch_status() { return hipGetLastError() == hipSuccess ? GP_OK : GP_ELAUNCH; }
 
+// Compute units of the current device (MI355X: 256 in 8 XCDs), queried once: persistent grids are sized from it.
+static inline int gp_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Keeps an early-requested value where it was requested: without it hipcc sinks the load next to its first use.

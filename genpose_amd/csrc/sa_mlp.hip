@@ -293,7 +293,7 @@ int launch_point_linear_ws(int rows, int n_out, const float *x, const float *wpa
     const int ntiles = (rows + R - 1) / R, nsplit = n_out / (64 * NCW);
     // persistent: WGS workgroups per CU over all channel splits, so that the splits of a tile run side by side and share its rows in the
     // L2 (a multiple of 8 in x keeps them on one XCD: the linear workgroup index is dealt round-robin over the eight)
-    int gx = 256 * WGS / nsplit;
+    int gx = gp_num_cus() * WGS / nsplit;
     gx = ntiles < gx ? ntiles : gx;
     if (gx >= 8) gx &= ~7;
     hipLaunchKernelGGL((point_linear_ws_kernel<KB, NCW, PT, PF, WGS>), dim3(gx, nsplit), dim3(256), lds, st, rows, n_out, x, wpack, z, ntiles);
@@ -710,7 +710,7 @@ int launch_chain_lds(const SAPreArgs &a, int b, hipStream_t st) {
     const int ncentres = b * a.np;
     const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;
     int blocks = (ncentres + 3) / 4;
-    if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // persistent: weights are staged once per workgroup
+    if (blocks > gp_num_cus() * per_cu) blocks = gp_num_cus() * per_cu;  // persistent: weights are staged once per workgroup
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a, ncentres);
     return gp_launch_status();
 }
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
     };
     // register budget (256 at two waves per SIMD): the operands of the NEXT chunk are requested into the same registers
     // right after layer 1 has consumed the current ones (the ~40 k cycles of layers 2-3 cover the latency); biases are
-    // re-read from L1/L2 where they are used; the running max of a two-chunk neighbourhood round-trips through `out`.
+    // re-read from L1/L2 where they are used; the running max of a two-chunk neighbourhood is one register per output chunk (`res`).
     int jn;
     float dcur[3];
     f32x4 zcur[Q1];
@@ -1088,7 +1088,7 @@ int launch_groupall_ring(const SAPreArgs &a, int b, hipStream_t st) {
             return GP_ELAUNCH;
         done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(b < 256 ? b : 256), dim3(512), lds, st, a, b);
+    hipLaunchKernelGGL(kern, dim3(b < gp_num_cus() ? b : gp_num_cus()), dim3(512), lds, st, a, b);
     return gp_launch_status();
 }
 
@@ -1106,7 +1106,7 @@ int launch_chain_ring(const SAPreArgs &a, int b, hipStream_t st) {
     }
     const int ncentres = b * a.np;
     int blocks = (ncentres + 7) / 8;
-    if (blocks > 256) blocks = 256;  // persistent, one 8-wave workgroup per CU (154 KB LDS)
+    if (blocks > gp_num_cus()) blocks = gp_num_cus();  // persistent, one 8-wave workgroup per CU (154 KB LDS)
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, a, ncentres);
     return gp_launch_status();
 }
@@ -1115,7 +1115,7 @@ template <int C1, int C2, int C3, int NS>
 int launch_chain(const SAPreArgs &a, int b, hipStream_t st) {
     const int ncentres = b * a.np;
     int blocks = (ncentres + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: <= 8 workgroups per CU resident, weights loaded once per wave
+    if (blocks > gp_num_cus() * 8) blocks = gp_num_cus() * 8;  // grid-stride: <= 8 workgroups per CU resident, weights loaded once per wave
     hipLaunchKernelGGL((sa0_chain_kernel<C1, C2, C3, NS>), dim3(blocks), dim3(256), 0, st, a, ncentres);
     return gp_launch_status();
 }
@@ -1217,8 +1217,8 @@ int gp_sa_pre_mlp_max_layout(int hidden_layout, int b, int n, int np, int ns, in
         // At 320 clouds: 256 + 64 -> 102 + 33 us and 150 + 52 us against 167 and 261 us for tiles alone.
         int nring = 0;
         if (z && n == 128 && c1 == 256 && c3 == 512 && (c2 == 256 || c2 == 384)) {
-            const int full = (b / 256) * 256;
-            nring = b - full >= 192 ? b : full;
+            const int ncu = gp_num_cus(), full = (b / ncu) * ncu;
+            nring = b - full >= (3 * ncu) / 4 ? b : full;
         }
         if (nring > 0) {
             const int rc = c2 == 256 ? launch_groupall_ring<256, 256, 512>(a, nring, (hipStream_t)s) : launch_groupall_ring<256, 384, 512>(a, nring, (hipStream_t)s);

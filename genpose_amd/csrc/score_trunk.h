@@ -320,7 +320,7 @@ constexpr size_t trunk_lds_bytes() {
 //     16       26.1   50.8   96.8   95.0  180.5  346
 //     32       39.7   39.7   75.0   74.8  146.6  290
 //     128     137.2  137.9  139.4  138.6  138.6  278
-// i.e. a ROUND of <= 256 workgroups costs 24.5 / 37.5 / 138.6 us; the plan with the smallest predicted launch time is taken.
+// i.e. a ROUND of one workgroup per CU (256 on MI355X) costs 24.5 / 37.5 / 138.6 us; the plan with the smallest predicted launch time is taken.
 constexpr float TILE16_ROUND_US = 24.5f, TILE32_ROUND_US = 37.5f, CHAIN128_ROUND_US = 138.6f;
 static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
     // a workgroup never straddles two batches; the chain form stages cvec + tvec of <= 4 clouds per workgroup (trunk_chain.h: NCL)
@@ -328,10 +328,11 @@ static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
         return (rows_per_group <= 0 || rows_per_group % rows == 0) && (rows < 128 || (rows - 2 + kcand) / kcand + 1 <= 4);
     };
     const float inf = 1e30f;
+    const int ncu = gp_num_cus();  // a round = one workgroup per CU
     const int t16 = (nrows + 15) / 16, t32 = (nrows + 31) / 32, w128 = (nrows + 127) / 128;
-    const float c16 = fits(16) ? TILE16_ROUND_US * ((t16 + 255) / 256) : inf;
-    const float c32 = fits(32) ? TILE32_ROUND_US * ((t32 + 255) / 256) : inf;
-    const float c128 = fits(128) ? CHAIN128_ROUND_US * ((w128 + 255) / 256) : inf;
+    const float c16 = fits(16) ? TILE16_ROUND_US * ((t16 + ncu - 1) / ncu) : inf;
+    const float c32 = fits(32) ? TILE32_ROUND_US * ((t32 + ncu - 1) / ncu) : inf;
+    const float c128 = fits(128) ? CHAIN128_ROUND_US * ((w128 + ncu - 1) / ncu) : inf;
     int best = 16;
     float cb = c16;
     if (c32 < cb) best = 32, cb = c32;
@@ -340,7 +341,8 @@ static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
 }
 // tile form only (entry points that have no chain form: ragged RK45 groups, the backward kernels)
 static inline int score_tile_rows(int nrows) {
-    const int r16 = ((nrows + 15) / 16 + 255) / 256, r32 = ((nrows + 31) / 32 + 255) / 256;
+    const int ncu = gp_num_cus();
+    const int r16 = ((nrows + 15) / 16 + ncu - 1) / ncu, r32 = ((nrows + 31) / 32 + ncu - 1) / ncu;
     return TILE32_ROUND_US * r32 < TILE16_ROUND_US * r16 ? 32 : 16;
 }
 

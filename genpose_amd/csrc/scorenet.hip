@@ -583,22 +583,30 @@ int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int
 int gp_pc_step_coupled(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
                        float *x, float *mean_x, float *score, float *partials, float *traj, const float *gn_ext, gp_stream_t s) {
-    return gp_pc_step_plan(0, 0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
+    // the entry points that predate gp_pc_layout stay in the TILE form: `partials` keeps the size their contract states,
+    // nsteps x ngroups x ceil(rows per group / gp_pc_tile_rows) - the chain form writes one partial per wave and is reached through
+    // gp_pc_layout + gp_pc_step_plan only
+    const int legacy_tile = gp_pc_tile_rows(ngroups, nclouds_per_group, k);
+    if (legacy_tile < 0) return legacy_tile;
+    return gp_pc_step_plan(0, legacy_tile, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
                            partials, traj, gn_ext, 0, s);
 }
 
 int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor, const float *centre,
                        float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s) {
-    return gp_pc_step_plan(0, 0, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score,
-                           partials, traj, nullptr, 0, s);
+    const int legacy_tile = gp_pc_tile_rows(ngroups, nclouds_per_group, k);
+    if (legacy_tile < 0) return legacy_tile;
+    return gp_pc_step_plan(0, legacy_tile, ngroups, nclouds_per_group, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x,
+                           score, partials, traj, nullptr, 0, s);
 }
 
 int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec, const float *tvec_all,
                const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
                float *score, float *partials, float *traj, gp_stream_t s) {
-    return gp_pc_step_plan(0, 0, 1, nclouds, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x, score, partials, traj,
-                           nullptr, 0, s);
+    if (nclouds < 0 || k <= 0) return GP_EINVAL;
+    return gp_pc_step_plan(0, score_tile_rows(nclouds * k), 1, nclouds, k, step, nsteps, net, cvec, tvec_all, sched, z_langevin, z_predictor, centre, x, mean_x,
+                           score, partials, traj, nullptr, 0, s);
 }
 
 }  // extern "C"

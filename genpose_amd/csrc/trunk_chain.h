@@ -7,13 +7,16 @@
 //   * for v_mfma_f32_16x16x4_f32 with the weights as the A operand, the D fragment (lane = row, four consecutive channels of
 //     16-channel chunk nc) IS the B fragment the next layer needs for k-group nc, so 9 -> 256 -> 256 -> 768 chains in registers
 //     with no LDS activation traffic and no barrier between the layers of a row;
-//   * the weights stream through a 3-slot LDS ring shared by the four waves of the workgroup (one per SIMD, the whole 512-entry
+//   * the weights stream through a SIX-slot LDS ring shared by the four waves of the workgroup (one per SIMD, the whole 512-entry
 //     register file each), 65 slices of 16 KB (16 fragments of 64 lanes x 16 B) - one pass over the weights serves 64 * PT rows
-//     instead of 32 - with ONE barrier per slice; slice s + 2 is written while slice s is multiplied;
-//   * the three Linear(256, 3) output layers run on the matrix pipe as well (their three rows as a zero-padded 16-row A
-//     fragment against the post-ReLU head activations exactly as the accumulators hold them), one output chunk per ring step of
-//     the NEXT half-layer (two accumulator sets, ping-pong), so the epilogue runs in the shadow of the MFMAs.  No cross-wave or
-//     cross-lane reduction exists: a wave holds ALL channels of its rows, the outputs land in lane group 0.
+//     instead of 32; the slice three steps ahead is written while the current one is multiplied, ONE bare s_barrier every second
+//     step (geometry and its safety conditions: Cfg below);
+//   * the three Linear(256, 3) output layers run on the matrix pipe as well, as v_mfma_f32_4x4x1_16b_f32 (sixteen independent 4 x 4
+//     outer products, 8 cycles each): block b = lanes 4b .. 4b+3 = four rows of ONE lane group; A = the head's three output rows
+//     (+ a row of zeros) at the channel this lane group holds, B = the post-ReLU head activations exactly as the accumulators hold
+//     them; one output chunk per ring step of the NEXT half-layer (two accumulator sets, ping-pong), so the epilogue runs in the
+//     shadow of the MFMAs.  Lane (row, g) collects its row's three outputs over the channels of lane group g; the four lane groups
+//     are summed once per launch (two __shfl_xor steps on nine values).
 // A ring step is a hand-placed instruction stream: 16 slots of 4 * PT MFMAs with a little other work each (one weight fragment
 // request, a quarter of the ring refill, a piece of the previous half-layer's epilogue), pinned to its slot with scheduling
 // barriers and interleaved with the slot's MFMAs by sched_group_barrier - with one wave per SIMD nothing else hides a burst of
@@ -21,9 +24,10 @@
 // optimiser sinks to the end of a half-layer unless they are pinned, another 6 %).
 // The MFMA sequence per hidden accumulator (k-group major, jj = 0..3) is the tile form's, so pre-activations agree bit for bit; only
 // the order in which the 256 products of an output component are summed differs (1e-7 relative).
-// Measured (MI355X, 32 000 rows): 141.9 us per launch against 146.6 us for the 32-row tile form; ring steps run at 92 % of the MFMA
-// issue rate (what a bare v_mfma loop with LDS operand reads reaches with one wave per SIMD, scratch/occ/mfma_power.hip), the
-// rest is the prologue (operand requests, 64 KB of ring start-up: 4 %), the output-layer MFMAs (3.7 %) and the tail.
+// Measured (MI355X, 32 000 rows): 137-139 us per launch (0.78-0.79 of the fp32 MFMA peak) against 146.6 us for the 32-row tile form;
+// ring steps run at 0.90-0.92 of the MFMA issue rate (what a bare v_mfma loop with LDS operand reads reaches with one wave per SIMD,
+// scratch/occ/mfma_power.hip), the rest is the prologue (operand requests, ring start-up: 4 %), 250 workgroups on 256 CUs, the
+// sustained clock and the tail.
 #pragma once
 #include "score_trunk.h"
 

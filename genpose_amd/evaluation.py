@@ -112,6 +112,8 @@ def sort_sRT_by_energy(sRT, energy=None, RT_overlaps=None, ranker="energy_ranker
         e = energy
     elif ranker == "gt_ranker":
         e = -np.min(RT_overlaps, axis=1)
+    elif ranker == "random":
+        e = np.random.rand(n, K, 2)  # sgpa_utils.py:926-927: numpy's global generator (seed it for a repeatable ablation)
     else:
         raise NotImplementedError(ranker)
     s, se = sort_sRT(sRT, e)

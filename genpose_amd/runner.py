@@ -140,17 +140,19 @@ class _FrameGraphs:
         self.share = snet.pts_encoder.grouping_key() == enet.pts_encoder.grouping_key()
         self._a, self._b = {}, {}
 
+    SLOT = "frame-graphs"  # the replays write into encoder workspaces of their own: no ticket of the agent path ever points at them
+
     def _embed_body(self, pts):
         enc_s, enc_e = self.snet.pts_encoder, self.enet.pts_encoder
-        grouping = enc_s.prepare_grouping(pts) if self.share else None
-        cvec_s = self.snet.pose_score_net.cloud_embed(enc_s.forward(pts, grouping=grouping))
-        cvec_e = self.enet.pose_score_net.cloud_embed(enc_e.forward(pts, grouping=grouping))
+        grouping = enc_s.prepare_grouping(pts, slot=self.SLOT) if self.share else None
+        cvec_s = self.snet.pose_score_net.cloud_embed(enc_s.forward(pts, slot=self.SLOT, grouping=grouping))
+        cvec_e = self.enet.pose_score_net.cloud_embed(enc_e.forward(pts, slot=self.SLOT, grouping=grouping))
         return pts.mean(dim=1), cvec_s, cvec_e
 
     def embed(self, pts):
         """-> (centre [n,3], cvec of the score model [n,768], cvec of the energy model [n,768])"""
-        n = pts.shape[0]
-        ent = self._a.get(n)
+        key = (tuple(pts.shape), pts.dtype)
+        ent = self._a.get(key)
         if ent is None:
             buf = pts.clone()
             self._embed_body(buf)  # warm-up outside capture: workspaces, kernel attributes
@@ -158,7 +160,7 @@ class _FrameGraphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = self._embed_body(buf)
-            ent = self._a[n] = (g, buf, outs)
+            ent = self._a[key] = (g, buf, outs)
         g, buf, outs = ent
         buf.copy_(pts)
         g.replay()
@@ -174,8 +176,8 @@ class _FrameGraphs:
 
     def rank(self, pred, centre, cvec_e):
         """pred [n,K,9] f64 -> (energy [n,K,2], sorted_RTs [n,K,4,4], average_sRT [n,4,4])"""
-        n = pred.shape[0]
-        ent = self._b.get(n)
+        key = (tuple(pred.shape), pred.dtype)
+        ent = self._b.get(key)
         if ent is None:
             bufs = (pred.clone(), centre.clone(), cvec_e.clone())
             self._rank_body(*bufs)
@@ -183,7 +185,7 @@ class _FrameGraphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = self._rank_body(*bufs)
-            ent = self._b[n] = (g, bufs, outs)
+            ent = self._b[key] = (g, bufs, outs)
         g, bufs, outs = ent
         for b, v in zip(bufs, (pred, centre, cvec_e)):
             b.copy_(v)
@@ -224,7 +226,8 @@ class TrackingRunner:
         init_x[:, -3:] -= sample["pts_center"]
         K = self.repeat_num
         sel = max(1, int(self.ratio * K))
-        if self.use_graphs and self.score_agent.cfg.sampler_mode[0] == "ode":
+        # (a coupled agent - its batch sharded over a process group - keeps the agent path: the frame graphs build an uncoupled solver)
+        if self.use_graphs and self.score_agent.cfg.sampler_mode[0] == "ode" and getattr(self.score_agent.net, "coupling_group", None) is None:
             from .samplers import ODESampler
             net = self.score_agent.net
             net._need_weights()

@@ -149,6 +149,7 @@ class ODESampler:
     TRAJ_CAP = 192
     CHUNKS = (8, 12, 16, 24, 32, 40, 48, 64, 80, 96, 128)  # attempts per first replay
 
+    MAX_GRAPHS = 12  # captured attempt graphs kept per kind (each holds chunk x 8 kernel nodes)
     MODELS = {"score": 0, "energy": 1, "likelihood": 2}
 
     def __init__(self, net, B, K, device, use_graph=True, poll=8, groups=1, group_clouds=None, model="score", coupling_group=None, tile=0):
@@ -315,6 +316,13 @@ class ODESampler:
         # (solves of up to 64 attempts - tracking: 6-8, the benched ODE-100: 36 - get a graph of exactly one spare attempt: every attempt
         # launched on a finished solve is eight kernels that exit at once, ~35 us, and a coarse chunk list made 12 attempts out of 7)
         first = self.poll if expect is None else (expect + 1 if expect < 64 else next((c for c in self.CHUNKS if c >= expect + 2), self.CHUNKS[-1]))
+        if expect is not None and expect < 64 and self.use_graph:
+            # a solve whose attempt count drifts by one or two from frame to frame must not pay a capture (torch.cuda.graph synchronises
+            # the device) in the middle of a latency-critical frame: take an already captured graph with up to three more spare attempts
+            # (each is eight kernels that exit at once) before capturing a new size
+            have = [c for c in self._graphs.get(gname, {}) if first <= c <= first + 3]
+            if have:
+                first = min(have)
         while True:
             chunk = first if n_done == 0 else self.poll
             if self.use_graph:
@@ -328,6 +336,11 @@ class ODESampler:
                         for _ in range(chunk):
                             self._attempt(traj)
                     graphs[chunk] = g
+                    if len(graphs) > self.MAX_GRAPHS:  # bounded cache: drop the least recently captured size that is not in use now
+                        for c in list(graphs):
+                            if c not in (chunk, self.poll):
+                                del graphs[c]
+                                break
                 graphs[chunk].replay()
             else:
                 for _ in range(chunk):

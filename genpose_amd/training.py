@@ -284,25 +284,27 @@ SYMMETRIC = ("bottle", "can", "bowl")  # + a mug whose handle is not visible (ut
 
 
 def pose_errors(pred9, gt9, class_ids, handle_visibility, synset_names):
-    """get_metrics (utils/metrics.py:157-186, object-to-camera poses): rotation error in degrees - about the y axis only for the
-    symmetric categories - and translation error in centimetres, per row.  Host arithmetic in float64 like the reference's numpy."""
+    """get_metrics (utils/metrics.py:157-186, object-to-camera poses) -> compute_RT_errors (:76-118): rotation error in degrees - about
+    the y axis only for the symmetric categories - and translation error in centimetres, per row.  The reference hands float32 4x4
+    matrices to numpy, so the general branch (R1 R2^T, trace, arccos) and the shift are float32 arithmetic and only the symmetric branch
+    (R @ int64 y-axis) is promoted to float64; the same dtypes here, so that near-ties rank as they do there."""
     from . import rotation
-    R1 = rotation.get_rot_matrix(pred9[:, :6].float()).double().cpu().numpy()
-    R2 = rotation.get_rot_matrix(gt9[:, :6].float()).double().cpu().numpy()
-    T1, T2 = pred9[:, 6:].double().cpu().numpy(), gt9[:, 6:].double().cpu().numpy()
-    # the reference goes through float32 4x4 matrices and divides the rotations by cbrt(det) (metrics.py:100-103)
-    R1, R2, T1, T2 = (np.asarray(a, dtype=np.float32).astype(np.float64) for a in (R1, R2, T1, T2))
-    R1 = R1 / np.cbrt(np.linalg.det(R1))[:, None, None]
+    R1 = rotation.get_rot_matrix(pred9[:, :6].float()).float().cpu().numpy()
+    R2 = rotation.get_rot_matrix(gt9[:, :6].float()).float().cpu().numpy()
+    T1, T2 = pred9[:, 6:].float().cpu().numpy(), gt9[:, 6:].float().cpu().numpy()
+    R1 = R1 / np.cbrt(np.linalg.det(R1))[:, None, None]  # float32 (metrics.py:100-103)
     R2 = R2 / np.cbrt(np.linalg.det(R2))[:, None, None]
     ids = np.asarray(class_ids).reshape(-1).astype(np.int64)
     vis = np.asarray(handle_visibility).reshape(-1)
     names = np.asarray(synset_names)[ids]
     sym = np.isin(names, SYMMETRIC) | ((names == "mug") & (vis == 0))
-    y1, y2 = R1[:, :, 1], R2[:, :, 1]
+    y1, y2 = R1[:, :, 1].astype(np.float64), R2[:, :, 1].astype(np.float64)  # R @ np.array([0, 1, 0]): float32 @ int64 -> float64
     cos_sym = (y1 * y2).sum(-1) / (np.linalg.norm(y1, axis=-1) * np.linalg.norm(y2, axis=-1))
-    cos_full = (np.einsum("bij,bij->b", R1, R2) - 1.0) / 2.0  # trace(R1 R2^T)
-    theta = np.degrees(np.arccos(np.clip(np.where(sym, cos_sym, cos_full), -1.0, 1.0)))
-    shift = np.linalg.norm(T1 - T2, axis=-1) * 100.0
+    cos_full = (np.trace(np.matmul(R1, R2.transpose(0, 2, 1)), axis1=1, axis2=2) - np.float32(1)) / np.float32(2)
+    theta_sym = np.arccos(np.clip(cos_sym, -1.0, 1.0)) * 180 / np.pi
+    theta_full = (np.arccos(np.clip(cos_full, np.float32(-1.0), np.float32(1.0))) * np.float32(180) / np.float32(np.pi)).astype(np.float64)
+    theta = np.where(sym, theta_sym, theta_full)
+    shift = (np.linalg.norm(T1 - T2, axis=-1) * np.float32(100)).astype(np.float64)
     return theta, shift
 
 
@@ -409,12 +411,19 @@ class Trainer:
         self.clock["minibatch"] += 1
         self.clock["step"] += 1
 
+    def tock(self):
+        """End of an epoch (TrainClock.tock, utils/genpose_utils.py:82-84)."""
+        self.clock["epoch"] += 1
+        self.clock["minibatch"] = 0
+
     def update_learning_rate(self):
         """posenet_agent.py:543-550: linear warm-up over `warmup` steps, then exponential decay for as long as lr >= 1e-4."""
         group = self.optimizer.param_groups[-1]
         if self.clock["step"] <= self.warmup:
             group["lr"] = self.base_lr / self.warmup * self.clock["step"]
         elif not group["lr"] < 1e-4:
+            # WHEN the decay is applied belongs to the caller: the reference's loop calls this at the end of an epoch, after that epoch's
+            # optimizer steps (runners/trainer.py:296-303) - scheduler.step() then follows optimizer.step() as torch expects
             self.scheduler.step()
 
     # ------------------------------------------------------------------ losses

@@ -213,7 +213,10 @@ int gp_score_tile_rows(int nrows);
  *   step == nsteps: additionally writes mean_x (+centre, normalised: :157-158).
  * sched [nsteps][4] f32 = {sigma(t_i), g(t_i), step_size, sqrt(step_size)} (host schedule table);
  * tvec_all [nsteps][768] from gp_time_embed; z_* [nsteps][R][9] standard-normal draws; centre [nclouds][3];
- * traj: NULL or [nsteps][R][9] (in-process samples, centre added). */
+ * traj: NULL or [nsteps][R][9] (in-process samples, centre added).
+ * partials: [nsteps][ceil(R / gp_score_tile_rows(R))] floats.  gp_pc_step, gp_pc_step_grouped and gp_pc_step_coupled always run the TILE
+ * form (one partial per 16- / 32-row workgroup), so this size holds for every R; the chain form of large launches (one partial per
+ * wave) is reached through gp_pc_layout + gp_pc_step_plan, whose nparts_out is then the size to allocate. */
 int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec, const float *tvec_all,
                const float *sched, const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x,
                float *score, float *partials, float *traj, gp_stream_t s);
@@ -222,8 +225,9 @@ int gp_pc_step(int nclouds, int k, int step, int nsteps, const gp_scorenet *net,
  * noise: group-major).  Everything is row-local except the batch-mean gradient norm, which stays PER GROUP, so every
  * group's result is what gp_pc_step returns for it alone (up to the summation order of the norm partials); serving
  * several batches per launch lets the kernel use 32-row tiles or the chain form (MFMA-bound) where one batch only fills 16-row
- * tiles (weight-stream-bound).  Rows of one group must be a multiple of the plan's workgroup rows; partials: [nsteps][nparts] with
- * nparts from gp_pc_layout(0, ...).  gp_pc_tile_rows() = the TILE-form choice (16 or 32, or GP_EINVAL) the RK45 driver uses. */
+ * tiles (weight-stream-bound).  Rows of one group must be a multiple of the tile; partials: [nsteps][ngroups * ceil(rows per group /
+ * tile)] with tile = gp_pc_tile_rows() = the TILE-form choice (16 or 32, or GP_EINVAL), which gp_pc_step_grouped / _coupled run and the
+ * RK45 driver uses.  (gp_pc_layout + gp_pc_step_plan additionally offer the chain form, with their own partials size.) */
 int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k);
 int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const gp_scorenet *net, const float *cvec,
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor,

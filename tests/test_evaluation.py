@@ -42,6 +42,25 @@ def test_building_blocks(data):
     np.testing.assert_array_equal(ppm, g["blk_pose_pred_matches"])
 
 
+def test_random_ranker(data):
+    """ranker='random' (utils/sgpa_utils.py:926-927): the hypotheses are ranked by np.random.rand(pred_num, repeat_num, 2) - with the
+    generator seeded, exactly the ranking those draws give; any other name is refused."""
+    _, results = data
+    r = _first_rich(results)
+    sRT = r["multi_hypothesis_pred_RTs"]
+    n, K = sRT.shape[:2]
+    np.random.seed(5)
+    sel, avg, sel_e = ev.sort_sRT_by_energy(sRT.copy(), None, None, "random", 0.6, "average")
+    np.random.seed(5)
+    draws = np.random.rand(n, K, 2)
+    want, _, want_e = ev.sort_sRT_by_energy(sRT.copy(), draws, None, "energy_ranker", 0.6, "nearest")
+    np.testing.assert_array_equal(sel, want)
+    np.testing.assert_array_equal(sel_e, want_e)
+    assert avg.shape == (n, 4, 4) and not np.array_equal(sel, ev.sort_sRT_by_energy(sRT.copy(), r["energy"].copy(), None, "energy_ranker", 0.6, "nearest")[0])
+    with pytest.raises(NotImplementedError):
+        ev.sort_sRT_by_energy(sRT.copy(), r["energy"], None, "bogus", 0.6, "average")
+
+
 @pytest.mark.parametrize("mode", ["average", "nearest"])
 def test_compute_mAP_matches_reference(data, mode, tmp_path):
     g, results = data

@@ -116,3 +116,41 @@ def test_empty_frame_and_single_object_through_the_runners():
     assert trk.step([None, None, None]) == [None, None, None]
     res = SingleFrameRunner(sa, ea, repeat_num=6, T0=0.3, batch_size=4).infer(pts.cpu().numpy())
     assert res["average_sRT"].shape == (1, 4, 4) and np.isfinite(res["average_sRT"]).all()
+
+
+def test_legacy_pc_step_entry_points_keep_their_partials_contract():
+    """gp_pc_step / gp_pc_step_grouped predate the launch plans: a C caller sizes `partials` as nsteps x ceil(R / gp_score_tile_rows(R))
+    (include/genpose_hip.h).  At 32 050 rows the automatic plan is the chain form, which writes one partial per WAVE (1 004 of them);
+    the legacy entry points must stay in the tile form and inside the buffer their contract states - a guard band behind it stays
+    untouched - and give what the planned launch chain gives in that form."""
+    from genpose_amd import _lib
+    from genpose_amd.samplers import PCSampler, pc_schedule
+    from genpose_amd.scorenet import ScoreNetHIP
+    l = _lib.lib()
+    B, K, n = 641, 50, 2
+    R = B * K
+    tile = l.gp_score_tile_rows(R)
+    t_out, n_out = ctypes.c_int(0), ctypes.c_int(0)
+    assert l.gp_pc_layout(0, 0, 1, B, K, ctypes.byref(t_out), ctypes.byref(n_out)) == 0 and t_out.value == 128  # what the plan would take
+    nparts = (R + tile - 1) // tile
+    assert n_out.value > nparts
+    net = ScoreNetHIP(go.make_state_dict(0, "score"), "cuda")
+    gen = torch.Generator().manual_seed(9)
+    cvec = torch.randn(B, 768, generator=gen).cuda()
+    centre = (torch.randn(B, 3, generator=gen) * 0.3).cuda()
+    x0 = (torch.randn(R, 9, generator=gen) * 50.0).cuda()
+    z1, z2 = torch.randn(n, R, 9, generator=gen).cuda(), torch.randn(n, R, 9, generator=gen).cuda()
+    ts, sched = pc_schedule(n)
+    sched = sched.cuda()
+    tvec = net.time_embed(ts.cuda())
+    x, mean_x, score = x0.clone(), torch.empty(R, 9, device="cuda"), torch.empty(R, 9, device="cuda")
+    guard = 64
+    partials = torch.full((n * nparts + guard,), -123.0, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i in range(n + 1):
+        assert l.gp_pc_step(B, K, i, n, net.w.ref(), _p(cvec), _p(tvec), _p(sched), _p(z1), _p(z2), _p(centre), _p(x), _p(mean_x), _p(score),
+                            _p(partials), None, st) == 0
+    torch.cuda.synchronize()
+    assert bool((partials[n * nparts:] == -123.0).all()) and bool((partials[: n * nparts] != -123.0).all())
+    _, want = PCSampler(net, B, K, n, "cuda", tile=tile, use_graph=False).run(cvec, centre, x0, z1, z2)
+    assert torch.equal(mean_x, want)

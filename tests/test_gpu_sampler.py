@@ -89,17 +89,26 @@ def test_ode_golden(golden, case):
     assert abs(int(stats["nfev"]) - ref_nfev) <= 0.15 * ref_nfev, (stats["nfev"], ref_nfev)
     if first_diff is None:
         assert abs(int(stats["nfev"]) - ref_nfev) <= 6  # at most the last, ulp-sized step differs
-    if int(stats["nfev"]) == ref_nfev:
+    same_count = int(stats["nfev"]) == ref_nfev
+    if same_count:
         ref_t = g[f"{case}_eval_t"]
         # same accept/reject sequence, and every attempt starts where the reference's did: first stage evaluation of an
         # attempt sits at t + h/5 (Dormand-Prince c_2).  Step sizes follow err^(-1/5), so fp32-level differences in the
         # score move them by ~1e-3 relative late in the integration; the reference logged f32 times.
         assert [bool(a) for a in stats["log_acc"]] == _ref_accepts(ref_t)
         np.testing.assert_allclose(stats["log_t"] + 0.2 * stats["log_h"], ref_t[2:-1:6][: len(stats["log_t"])], rtol=2e-3, atol=2e-5)
-    if proc is not None and int(stats["nfev"]) == ref_nfev:
-        assert list(proc.shape) == list(g[f"{case}_proc_shape"])
-        ode_close(proc[:, :, -3:].cpu().numpy(), g[f"{case}_proc_last3"])
-        ode_close(proc[:, :, :2].cpu().numpy(), g[f"{case}_proc_first2"])
+        if proc is not None:
+            assert list(proc.shape) == list(g[f"{case}_proc_shape"])
+            ode_close(proc[:, :, -3:].cpu().numpy(), g[f"{case}_proc_last3"])
+            ode_close(proc[:, :, :2].cpu().numpy(), g[f"{case}_proc_first2"])
+    # which branch ran is part of the result: the non-chaotic cases must take the reference's evaluation count exactly (and with it
+    # the full-trajectory asserts above); only the chaotic T0 = 1 problems may drift late, inside the bounds asserted before
+    may_drift = float(g[f"{case}_T0"]) >= 1.0
+    assert same_count or may_drift, f"{case}: {stats['nfev']} evaluations against the reference's {ref_nfev} on a non-chaotic problem"
+    if not same_count:
+        import warnings
+        warnings.warn(f"test_ode_golden[{case}]: schedule drifted late (nfev {stats['nfev']} vs {ref_nfev}, first flip at attempt {first_diff}); "
+                      "end pose, leading attempts and evaluation-count bounds were checked, the full-trajectory asserts were not")
 
 
 def test_pc_agent_golden(golden):

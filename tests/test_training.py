@@ -163,6 +163,8 @@ def test_energy_training_step_on_the_cpu_with_the_c_operators(monkeypatch):
     assert set(tr.state_dict(ema=True)) == set(go.make_state_dict(0, "energy"))
 
 
+# the schedule is driven on its own here (no optimizer step in between): torch's order check does not apply to this test
+@pytest.mark.filterwarnings("ignore:Detected call of `lr_scheduler.step:UserWarning")
 def test_trainer_modes_schedule_and_checkpoints(tmp_path, monkeypatch):
     """gf_mode / network mismatches are refused; the learning rate warms up linearly and then decays while >= 1e-4
     (posenet_agent.py:543-550); save_ckpt / load_ckpt round-trip the reference's checkpoint dictionary and resume the optimiser."""
@@ -185,6 +187,8 @@ def test_trainer_modes_schedule_and_checkpoints(tmp_path, monkeypatch):
     np.testing.assert_allclose(lrs[:4], [2.5e-4, 5e-4, 7.5e-4, 1e-3])
     np.testing.assert_allclose(lrs[4:8], [5e-4, 2.5e-4, 1.25e-4, 6.25e-5])
     assert lrs[8] == lrs[7]  # below 1e-4 the decay stops
+    tr.tock()
+    assert tr.clock == {"epoch": 2, "minibatch": 0, "step": 9}  # TrainClock.tock (utils/genpose_utils.py:82-84)
     path = os.path.join(str(tmp_path), "ckpt_epoch1.pth")
     tr.save_ckpt(path)
     ck = torch.load(path)
