@@ -81,7 +81,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clouds", type=int, default=64, help="clouds of the CPU-baseline sample (BASELINE.md §3: one 64-cloud batch)")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work the baseline leg may spend")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / ODE-100 side measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / ODE-100 / drop-in side measurements")
+    ap.add_argument("--only-drop-in", action="store_true",
+                    help="run only the `drop_in_eval_single` leg (the reference's eval_single call sequence through the agent API) and print it - "
+                         "for rocprofv3 kernel statistics of that path")
     ap.add_argument("--tracking", action="store_true",
                     help="BASELINE configs[4]: tracking mode - every rank streams --sequences whole sequences (warm-started candidates, PF-ODE "
                          "sampler from T0 = 0.15, energy ranking, aggregation per frame); a step = one frame of every sequence")
@@ -140,6 +143,9 @@ def main():
     from genpose_amd.posenet_agent import PoseNet
     from genpose_amd.weights_synth import make_state_dict
 
+    if args.only_drop_in:
+        print(json.dumps({"drop_in_eval_single": drop_in_leg(torch, str(dev), args.cand)}), flush=True)
+        return
     if args.tracking:
         tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend)
         if dist is not None:
@@ -281,6 +287,7 @@ def main():
         if not args.no_secondary and args.pipeline == "score" and args.sampler == "pc" and not args.no_pipeline:
             side["ode_100"] = ode_leg(torch, B, K, G, T0, pool, str(dev))
             side["full_pipeline_256"] = full_pipeline_leg(torch, K, n, str(dev))
+            side["drop_in_eval_single"] = drop_in_leg(torch, str(dev), K)
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
@@ -294,7 +301,9 @@ def main():
             "metric": "poses/sec (1024-pt cloud, 50 cand x 100 SDE steps)", "value": round(value, 2), "unit": "poses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[{2 if energy_agent is not None else 1}]: {B} clouds/GPU x 1024 pts, {K} candidates, "
+            # the full pipeline on more than one GPU is BASELINE configs[3] (2048 clouds = 8 x 256, sharded, results gathered)
+            "config": {"workload": f"configs[{(3 if world > 1 else 2) if energy_agent is not None else 1}]: "
+                                   + (f"{world * B} clouds sharded over {world} GPUs = " if world > 1 else "") + f"{B} clouds/GPU x 1024 pts, {K} candidates, "
                                    + (f"PC sampler {n} steps (NFE={n})" if args.sampler == "pc" else f"ODE sampler RK45 T0={T0} (NFE={nfev})")
                                    + (", ScoreNet only" if energy_agent is None else ", + EnergyNet ranking + top-60% aggregation"),
                        "clouds_per_gpu": B, "candidates": K, "sde_steps": n, "sampler": args.sampler, "pipeline": args.pipeline,
@@ -531,6 +540,102 @@ def full_pipeline_leg(torch, K, n, dev, B=256):
             "workload": f"{B} clouds x {K} cand: encoder + PC-{n} sampler (score model) | encoder + energy (energy model) -> ranking -> top-60% aggregate",
             "flop_per_pose": 7.10e9, "whole_path_tflops": round(B * nb / dt * 7.10e9 / 1e12, 2),
             "executed_tflops": round(B * nb / dt * (7.10e9 - 2 * (FLOP_ENCODER - FLOP_ENCODER_EXECUTED)) / 1e12, 2)}
+
+
+class _HostSyncCounter:
+    """Counts the host-side waits for the device inside a block: torch.cuda.synchronize, Stream / Event.synchronize and the blocking
+    device-to-host reads (.cpu(), .item(), .tolist(), .numpy() of a device tensor)."""
+
+    def __init__(self, torch):
+        self.torch, self.n, self.saved = torch, 0, []
+
+    def _wrap(self, owner, name, only_cuda_tensor=False):
+        orig = getattr(owner, name)
+        counter = self
+
+        def wrapped(*a, **kw):
+            if not only_cuda_tensor or (a and getattr(a[0], "is_cuda", False)):
+                counter.n += 1
+            return orig(*a, **kw)
+        self.saved.append((owner, name, orig))
+        setattr(owner, name, wrapped)
+
+    def __enter__(self):
+        t = self.torch
+        self._wrap(t.cuda, "synchronize")
+        self._wrap(t.cuda.Stream, "synchronize")
+        self._wrap(t.cuda.Event, "synchronize")
+        for name in ("cpu", "item", "tolist", "numpy"):
+            self._wrap(t.Tensor, name, only_cuda_tensor=True)
+        return self
+
+    def __exit__(self, *exc):
+        for owner, name, orig in reversed(self.saved):
+            setattr(owner, name, orig)
+
+
+def drop_in_leg(torch, dev, K, B=256, T0=0.55):
+    """The call sequence a GenPose user gets from the one-line import swap of INTEGRATION.md §2, measured through the AGENT API only -
+    scripts/eval_single.sh:1-16 + runners/evaluation_single.py:309-353,356-489: batches of 256 instances, K = 50 candidates,
+        pred = score_agent.pred_func(data, repeat_num=K, T0=0.55)         # ODE sampler (the script's default), adaptive RK45
+        energy = energy_agent.get_energy(data, pose_samples=pred, T=1e-5)
+        rank + top-60 % aggregation
+    one batch per call, nothing shared between calls, no request batching, no predictor object.  Also with the PC-100 sampler (the
+    benched sampler) and, beside it, FullPipelinePredictor.run on the same batches (one batch per launch): what the agent path gives up
+    against the predictor that overlaps the energy encoder with the sampler."""
+    from genpose_amd import reward, synth
+    from genpose_amd.config import get_config
+    from genpose_amd.pipeline import FullPipelinePredictor
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.runner import make_batch_sample
+    from genpose_amd.weights_synth import make_state_dict
+    pool = [torch.from_numpy(synth.make_batch(B, start=20000 + B * j)).to(dev) for j in range(4)]
+    ea = PoseNet(get_config(device=dev, posenet_mode="energy"))
+    ea.load_state_dict(make_state_dict(0, "energy"))
+    out = {"workload": f"{B} clouds x {K} cand per call: PoseNet.pred_func -> PoseNet.get_energy -> rank_aggregate(ratio=0.6), agent API only "
+                       "(scripts/eval_single.sh, evaluation_single.py:356-489)"}
+    nb = 12
+    for name, sampler, steps in (("ode_T0_0.55", "ode", None), ("pc_100", "pc", 100)):
+        sa = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=[sampler], sampling_steps=steps))
+        sa.load_state_dict(make_state_dict(0, "score"))
+
+        def call(pts):
+            data = make_batch_sample(pts)  # evaluation_single.py:394-403
+            pred = sa.pred_func(data=data, repeat_num=K, save_path=None, T0=T0)
+            energy = ea.get_energy(data=data, pose_samples=pred, T=1e-5)
+            return reward.rank_aggregate(pred, energy, ratio=0.6)["avg_pose"]
+
+        for j in range(4):
+            call(pool[j % len(pool)])  # builds the samplers, captures the graphs (encoder passes from the second call on)
+        torch.cuda.synchronize()
+        with _HostSyncCounter(torch) as hs:
+            t0 = time.perf_counter()
+            for j in range(nb):
+                call(pool[j % len(pool)])
+            issued = time.perf_counter() - t0
+            nsync = hs.n
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        leg = {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_call": round(dt / nb * 1e3, 3), "host_syncs_per_call": round(nsync / nb, 2),
+               "host_issue_ms_per_call": round(issued / nb * 1e3, 3), "sampler": sampler}
+        if sampler == "ode":
+            st = sa.net.last_sampler.last_stats
+            leg["nfev"], leg["attempts"] = int(st["nfev"]), int(st["n_attempts"])
+            leg["replays"] = dict(sa.net.last_sampler.last_replays)
+        else:
+            fp = FullPipelinePredictor(sa, ea, B, K, steps)
+            for j in range(3):
+                fp.run(pool[j % len(pool)])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for j in range(nb):
+                fp.run(pool[j % len(pool)])
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            leg["predictor_one_batch_per_launch"] = {"value": round(B * nb / d1, 2), "ms_per_call": round(d1 / nb * 1e3, 3)}
+            leg["agent_over_predictor"] = round(d1 / dt, 4)
+        out[name] = leg
+    return out
 
 
 def run_cpu_baseline(torch, args, K, n):

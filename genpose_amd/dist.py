@@ -30,13 +30,18 @@ def all_gather_ragged(t, n_total, group=None):
     pad = max_len - t.shape[0]
     if pad > 0:
         t = torch.cat([t, t.new_zeros((pad,) + tuple(t.shape[1:]))], dim=0)
+    # RCCL (backend 'nccl') gathers device tensors in place; gloo has no all_gather for device tensors (the one-device rehearsal of the
+    # N-rank job and the CPU tests run on it): stage through the host there and bring the result back
+    home = t.device
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        t = t.cpu()
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t.contiguous(), group=group)
     pieces = []
     for r in range(world):
         s, e = shard_bounds(n_total, r, world)
         pieces.append(out[r][: e - s])
-    return torch.cat(pieces, dim=0)
+    return torch.cat(pieces, dim=0).to(home)
 
 
 class ShardedInference:
@@ -120,8 +125,11 @@ class ShardedTracking:
             outs = self.tracker.step(frames)
             for s, o in zip(self.owned(), outs):
                 if o is not None:
-                    local[s].append({k: o[k].detach().cpu() for k in keys})
+                    # device-side copies: nothing in the streaming loop waits for the GPU (a .cpu() here is a synchronisation per
+                    # sequence and frame); the results come down once, after the last frame
+                    local[s].append({k: o[k].detach().clone() for k in keys})
             t += 1
+        local = {s: [{k: v.cpu() for k, v in fr.items()} for fr in frs] for s, frs in local.items()}
         if not gather or self.world == 1:
             return local
         parts = [None] * self.world

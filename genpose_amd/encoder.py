@@ -136,6 +136,48 @@ class Pointnet2EncoderHIP:
         return (ticket is not None and ticket["key"] == key and ticket["pts"]() is pts and ticket["version"] == pts._version
                 and ticket["shape"] == tuple(pts.shape) and ticket["ws"].get("_gen") == ticket["gen"])
 
+    MAX_PASS_GRAPHS = 8
+
+    def encode(self, pts, grouping=None, use_graph=True):
+        """The whole encoder pass of an AGENT call (GFObjectPose.extract_pts_feature) as one hipGraph replay per input shape:
+            grouping None  ->  prepare_grouping + forward: returns (feat [B,1024], workspace) - the workspace is what a second encoder takes
+                               over (grouping_ticket);
+            grouping = ws  ->  forward on those centres and neighbourhoods: returns feat.
+        ~25 launches replayed instead of issued (they dominate a small batch: a 5-cloud pass is launch-bound).  The first call of a shape
+        runs launch by launch (warm-up; a shape seen once never pays a capture), the second captures, later ones copy the clouds into the
+        graph's static input and replay.  Results are the launch-by-launch pass's, bit for bit (same kernels, same order)."""
+        direct = (lambda: self.forward(pts, grouping=grouping)) if grouping is not None else (lambda: self._forward_with_grouping(pts))
+        if not use_graph or not pts.is_cuda or torch.cuda.is_current_stream_capturing():
+            return direct()
+        if not hasattr(self, "_pass_graphs"):
+            self._pass_graphs = {}
+        key = (tuple(pts.shape), id(grouping) if grouping is not None else None)
+        ent = self._pass_graphs.get(key)
+        if ent is None:
+            if len(self._pass_graphs) >= self.MAX_PASS_GRAPHS:
+                self._pass_graphs.pop(next(iter(self._pass_graphs)))
+            self._pass_graphs[key] = {"graph": None}
+            return direct()
+        self._pass_graphs[key] = self._pass_graphs.pop(key)  # most recently used last
+        if ent["graph"] is None:
+            buf = pts[..., 0:3].contiguous().clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.forward(buf, grouping=grouping) if grouping is not None else self._forward_with_grouping(buf)
+            ent.update(graph=g, buf=buf, out=out, grouping=grouping)  # `grouping` is kept alive: its id() is part of the key
+        ent["buf"].copy_(pts[..., 0:3])
+        if grouping is None:
+            ent["out"][1]["_gen"] = next(_GENERATION)  # the replay rewrites the grouping buffers: tickets for the previous contents die here
+            ent["graph"].replay()
+            return ent["out"][0].clone(), ent["out"][1]
+        ent["graph"].replay()
+        return ent["out"].clone()
+
+    def _forward_with_grouping(self, pts):
+        ws = self.prepare_grouping(pts)
+        return self.forward(pts, grouping=ws), ws
+
     def forward(self, pts, return_intermediates=False, slot=0, centres_done=False, grouping=None):
         """grouping: workspace returned by prepare_grouping() of an encoder with the same grouping configuration, for the SAME
         clouds: its centres and neighbourhood indices are used instead of being recomputed."""

@@ -60,17 +60,17 @@ class GFObjectPose:
             raise RuntimeError("GFObjectPose has no weights: call load_state_dict()/PoseNet.load_ckpt() first")
 
     # ------------------------------------------------------------------ pieces
-    def extract_pts_feature(self, data):
+    def extract_pts_feature(self, data, use_graph=True):
         """posenet.py:71-91.  The sampled centres and ball-query neighbourhoods depend on the coordinates only, so the SCORE agent
         leaves a ticket for them in the dict (`_grouping`) and the ENERGY agent, called next with the same dict and the same clouds
         (evaluation_single.py:339-343, evaluation_tracking.py:316-321), takes them over instead of recomputing them."""
         self._need_weights()
         enc, pts = self.pts_encoder, data["pts"]
         if self.cfg.posenet_mode == "energy" and enc.ticket_valid(data.get("_grouping"), pts, enc.grouping_key()):
-            return enc.forward(pts, grouping=data["_grouping"]["ws"])
-        ws = enc.prepare_grouping(pts)
-        data["_grouping"] = enc.grouping_ticket(pts, ws)
-        return enc.forward(pts, grouping=ws)
+            return enc.encode(pts, grouping=data["_grouping"]["ws"], use_graph=use_graph and data["_grouping"].get("use_graph", True))
+        feat, ws = enc.encode(pts, use_graph=use_graph)  # one hipGraph replay per input shape from the second call on (encoder.py)
+        data["_grouping"] = dict(enc.grouping_ticket(pts, ws), use_graph=use_graph)  # the second agent follows the first one's choice
+        return feat
 
     def _rows(self, data):
         """-> (cvec [B,768], K, centre [B,3] or None)"""

@@ -317,7 +317,8 @@ class MultiSequenceTracker:
         init_x[:, -3:] -= centre
         # ---- score model: encoder -> warm-started ODE, one group per sequence
         shared = {"pts": pts, "pts_center": centre}
-        feat = net.extract_pts_feature(shared)  # leaves the grouping ticket for the energy agent
+        # (launch by launch: the cloud count of a multi-sequence step changes from frame to frame and the pass is not launch-bound here)
+        feat = net.extract_pts_feature(shared, use_graph=False)  # leaves the grouping ticket for the energy agent
         cvec = net.pose_score_net.cloud_embed(feat)
         B = pts.shape[0]
         if prior is None:

@@ -71,3 +71,61 @@ def test_config4_tracking_two_ranks_on_one_device():
     line = json.loads(lines[0])
     assert REQUIRED <= set(line) and line["n_gpus"] == 2 and line["config"]["sequences_per_gpu"] == 3 and line["config"]["sampler"] == "ode"
     assert line["value"] > 0 and abs(line["value"] - 2 * 3 * 2 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Rehearsal of the 8-rank job (BASELINE configs[3] / configs[4]): the box has one GPU, so the eight ranks share cuda:0 and the
+# collectives run on gloo - everything else (launcher, rank environment, sharding, barriers, MAX-reduced timing, the gather of the
+# results, rank 0's one JSON line) is the code path the driver's `--gpus 8` run takes on an 8-GPU node.
+def _run_raw(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_eight_ranks_plain_workload_on_one_device():
+    line = _run(["--gpus", "8"], {"GP_BENCH_ONE_DEVICE": "1"})
+    assert REQUIRED <= set(line) and line["n_gpus"] == 8
+    assert line["launch"] == {"mode": "self", "world_size_observed": 8, "backend": "gloo"}
+    assert line["scaling"] == "weak" and line["config"]["clouds_per_gpu"] == 8 and line["config"]["parallelism"] == "clouds sharded x8"
+    assert abs(line["value"] - 8 * 8 * 2 / (line["ms_per_step"] * 2e-3)) <= 0.01 * line["value"]  # whole-job aggregate over the eight ranks
+
+
+def test_config3_eight_ranks_2048_clouds_full_pipeline_on_one_device():
+    """BASELINE configs[3] at its real shape: 8 ranks x 256 clouds = 2048 clouds per step, 50 candidates x 100 PC steps, energy ranking
+    and aggregation, one gather of the aggregated poses per batch."""
+    line = _run_raw(["--gpus", "8", "--pipeline", "full", "--batch", "256", "--steps", "2", "--warmup", "1", "--repeats", "1",
+                     "--batches-per-launch", "1", "--no-cpu-baseline", "--no-secondary"], {"GP_BENCH_ONE_DEVICE": "1"})
+    assert REQUIRED <= set(line) and line["n_gpus"] == 8 and line["launch"]["world_size_observed"] == 8
+    c = line["config"]
+    assert c["pipeline"] == "full" and c["clouds_per_gpu"] == 256 and c["candidates"] == 50 and c["sde_steps"] == 100
+    assert c["workload"].startswith("configs[3]: 2048 clouds sharded over 8 GPUs = 256 clouds/GPU") and "EnergyNet ranking" in c["workload"]
+    assert abs(line["value"] - 8 * 256 * 2 / (line["ms_per_step"] * 2e-3)) <= 0.01 * line["value"]  # 2048 clouds per step
+
+
+def test_config4_tracking_eight_ranks_on_one_device():
+    line = _run_raw(["--gpus", "8", "--tracking", "--sequences", "2", "--objects", "2", "--cand", "10", "--steps", "3", "--warmup", "2", "--repeats", "1"],
+                    {"GP_BENCH_ONE_DEVICE": "1"})
+    assert REQUIRED <= set(line) and line["n_gpus"] == 8 and line["launch"]["world_size_observed"] == 8
+    assert line["config"]["sequences_per_gpu"] == 2 and line["config"]["parallelism"] == "whole sequences per rank x8 (replicas only)"
+    assert line["value"] > 0 and abs(line["value"] - 8 * 2 * 2 * 3 / (line["ms_per_step"] * 3e-3)) <= 0.01 * line["value"]
+
+
+def test_one_rank_on_rccl_costs_nothing():
+    """GP_BENCH_FORCE_DIST=1: the N = 1 workload with the process group up on RCCL (backend 'nccl') - barrier, all-gather of every result and
+    the MAX all-reduce of the block time inside the timed region.  The distributed plumbing must not cost throughput: the line stays within
+    2 % of the plain N = 1 line (measured: < 1 %; the bound leaves room for box-to-box noise)."""
+    common = ["--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-secondary"]
+    plain = _run_raw(common)
+    rccl = _run_raw(common, {"GP_BENCH_FORCE_DIST": "1"})
+    assert plain["launch"]["backend"] is None and rccl["launch"] == {"mode": "direct", "world_size_observed": 1, "backend": "nccl"}
+    assert plain["config"] == rccl["config"] and plain["n_gpus"] == rccl["n_gpus"] == 1
+    ratio = rccl["value"] / plain["value"]
+    print(f"one rank on RCCL: {rccl['value']:.0f} poses/s against {plain['value']:.0f} plain ({100 * (ratio - 1):+.2f} %)")
+    assert ratio > 0.98, (rccl["value"], plain["value"])

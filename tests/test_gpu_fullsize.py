@@ -336,3 +336,61 @@ def test_config2_run_many_as_timed():
     avg = m["avg_pose"][sl].cpu().numpy()
     np.testing.assert_allclose(avg[:, 4:], qt.numpy()[:, 4:], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(qt.numpy()[:, 4:]).max())))
     assert np.all(np.abs(np.sum(avg[:, :4] * qt.numpy()[:, :4], axis=1)) > 1 - 1e-5)
+
+
+def test_drop_in_eval_single_as_timed():
+    """The reference's own evaluation call sequence at its own batch shape, through the AGENT API only, exactly as bench.py's
+    `drop_in_eval_single` leg times it (scripts/eval_single.sh + evaluation_single.py:356-489): 256 clouds per batch, K = 50,
+    pred_func with the ODE sampler from T0 = 0.55 (adaptive RK45 over all 12 800 coupled rows) -> get_energy(T = 1e-5) -> ranking ->
+    top-60 % aggregation.  Three calls: launch by launch, the call that captures the encoder passes, a replay - identical bits; then
+    against the CPU oracle: the solver's evaluation count and the poses of ALL 12 800 rows (the batch-global error norm couples
+    them), energies and aggregation on a 16-cloud slice, encoder features on a 32-cloud slice."""
+    from genpose_amd import reward, synth
+    from genpose_amd.runner import make_batch_sample
+    B, K, T0 = 256, 50, 0.55
+    sa, ea = make_agent("score", "ode", None), make_agent("energy")
+    pts = torch.from_numpy(synth.make_batch(B, start=20000)).cuda()
+    prior = torch.randn(B * K, 9, generator=torch.Generator().manual_seed(11))
+    sa.net.prior_fn = lambda shape, T=1.0: prior * (0.01 * 5000.0 ** T)
+    runs = []
+    for _ in range(3):
+        data = make_batch_sample(pts)
+        pred = sa.pred_func(data=data, repeat_num=K, save_path=None, T0=T0)
+        energy = ea.get_energy(data=data, pose_samples=pred, T=1e-5)
+        r = reward.rank_aggregate(pred, energy, ratio=0.6)
+        runs.append((pred.clone(), energy.clone(), r["order"].clone(), r["avg_pose"].clone(), data["pts_feat"].clone(),
+                     int(sa.net.last_sampler.last_stats["nfev"])))
+    torch.cuda.synchronize()
+    assert all(ent.get("graph") is not None for ent in sa.net.pts_encoder._pass_graphs.values())  # the passes are graph replays by now
+    assert all(ent.get("graph") is not None for ent in ea.net.pts_encoder._pass_graphs.values())
+    for later in runs[1:]:
+        for a, b in zip(runs[0][:5], later[:5]):
+            assert torch.equal(a, b)
+        assert later[5] == runs[0][5]
+    pred, energy, order, avg, feat, nfev = runs[0]
+    assert pred.dtype == torch.float64 and pred.shape == (B, K, 9) and energy.shape == (B, K, 2)
+    _check_pose_properties(pred.float())
+    # ---- oracle
+    sd, sde = go.make_state_dict(0, "score"), go.make_state_dict(0, "energy")
+    pts_cpu = pts.cpu()
+    ref_feat = torch.cat([go.encoder_forward(sd, pts_cpu[s:s + 32]) for s in range(0, B, 32)], dim=0)
+    np.testing.assert_allclose(feat.cpu().numpy(), ref_feat.numpy(), rtol=ENC_RTOL, atol=ENC_ATOL)
+    feat_r = ref_feat.repeat_interleave(K, 0)
+    cen = pts_cpu.mean(dim=1)
+    _, ref_x, ref_nfev = go.ode_sampler(lambda x, t: go.score_forward(sd, feat_r, x, t), prior * go.ve_sigma(T0),
+                                        cen.repeat_interleave(K, 0), T0)
+    assert abs(nfev - ref_nfev) <= 6, (nfev, ref_nfev)  # at most one attempt of difference (an error norm within round-off of 1)
+    got, ref = pred.cpu().numpy().reshape(B * K, 9), ref_x.numpy()
+    np.testing.assert_allclose(got[:, :6], ref[:, :6], rtol=0, atol=2e-3, err_msg="rotation block, 12800 rows")
+    np.testing.assert_allclose(got[:, 6:], ref[:, 6:], rtol=0, atol=5e-4 * np.abs(ref[:, 6:]).max(), err_msg="translations")
+    sl = slice(64, 80)
+    ref_e = go.get_energy(sde, pts_cpu[sl], cen[sl], pred[sl].cpu(), T=1e-5).numpy()
+    np.testing.assert_allclose(energy[sl].cpu().numpy(), ref_e, rtol=5e-4, atol=5e-4 * np.abs(ref_e).max())
+    e_cpu = energy.cpu()
+    for c in range(2):
+        assert torch.equal(order[:, :, c].cpu().long(), torch.sort(e_cpu[:, :, c], dim=1, descending=True, stable=True).indices)
+    sorted_poses = reward.rank_aggregate(pred, energy, ratio=0.6)["sorted_poses"]
+    _, qt = go.aggregate_sorted(go.pose9_to_RT(sorted_poses[sl].cpu()), ratio=0.6)
+    a = avg[sl].cpu().numpy()
+    np.testing.assert_allclose(a[:, 4:], qt.numpy()[:, 4:], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(qt.numpy()[:, 4:]).max())))
+    assert np.all(np.abs(np.sum(a[:, :4] * qt.numpy()[:, :4], axis=1)) > 1 - 1e-5)
