@@ -288,6 +288,7 @@ def main():
             side["ode_100"] = ode_leg(torch, B, K, G, T0, pool, str(dev))
             side["full_pipeline_256"] = full_pipeline_leg(torch, K, n, str(dev))
             side["drop_in_eval_single"] = drop_in_leg(torch, str(dev), K)
+            side["config0_single_object"] = config0_leg(torch, str(dev), cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
@@ -635,6 +636,65 @@ def drop_in_leg(torch, dev, K, B=256, T0=0.55):
             leg["predictor_one_batch_per_launch"] = {"value": round(B * nb / d1, 2), "ms_per_call": round(d1 / nb * 1e3, 3)}
             leg["agent_over_predictor"] = round(d1 / dt, 4)
         out[name] = leg
+    return out
+
+
+def config0_leg(torch, dev, cpu=True):
+    """BASELINE configs[0] - the reference's own CPU-runnable case: ONE cloud x 1024 pts, 10 candidates, 20 SDE steps (PC) and the default
+    adaptive ODE solve (T0 = 0.55), evaluation_single.py call sequence through the agent API: latency per call on the device (the work of a
+    call is far too small to fill the chip: this is a latency figure, not a throughput one), and the oracle on the host beside it."""
+    from genpose_amd import reward, synth
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.runner import make_batch_sample
+    from genpose_amd.weights_synth import make_state_dict
+    B, K = 1, 10
+    pool = [torch.from_numpy(synth.make_batch(B, start=30000 + j)).to(dev) for j in range(4)]
+    ea = PoseNet(get_config(device=dev, posenet_mode="energy"))
+    ea.load_state_dict(make_state_dict(0, "energy"))
+    out = {"workload": "1 cloud x 1024 pts, 10 candidates per call: pred_func -> get_energy -> rank_aggregate (agent API)"}
+    for name, sampler, steps in (("pc_20", "pc", 20), ("ode_T0_0.55", "ode", None)):
+        sa = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=[sampler], sampling_steps=steps))
+        sa.load_state_dict(make_state_dict(0, "score"))
+
+        def call(pts):
+            data = make_batch_sample(pts)
+            pred = sa.pred_func(data=data, repeat_num=K, save_path=None, T0=0.55)
+            energy = ea.get_energy(data=data, pose_samples=pred, T=1e-5)
+            return reward.rank_aggregate(pred, energy, ratio=0.6)["avg_pose"]
+
+        for j in range(6):
+            call(pool[j % 4])
+        torch.cuda.synchronize()
+        nb = 40
+        t0 = time.perf_counter()
+        for j in range(nb):
+            call(pool[j % 4])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nb
+        out[name] = {"ms_per_call": round(dt * 1e3, 3), "poses_per_s": round(B / dt, 1)}
+        if sampler == "ode":
+            out[name]["nfev"] = int(sa.net.last_sampler.last_stats["nfev"])
+    if cpu:
+        from oracle import genpose_oracle as go
+        sd, sde = go.make_state_dict(0, "score"), go.make_state_dict(0, "energy")
+        pts = pool[0].cpu()
+        gen = torch.Generator().manual_seed(0)
+        prior, z1, z2 = torch.randn(K, 9, generator=gen), torch.randn(20, K, 9, generator=gen), torch.randn(20, K, 9, generator=gen)
+        saved = torch.get_num_threads()
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
+        try:
+            for name, smp, kw in (("pc_20", "pc", dict(sampling_steps=20, z_langevin=z1, z_predictor=z2)), ("ode_T0_0.55", "ode", dict(T0=0.55))):
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    pred, _, _ = go.pred_func(sd, pts, pts.mean(dim=1), K, smp, prior, **kw)
+                    go.get_energy(sde, pts, pts.mean(dim=1), pred, T=1e-5)
+                    ts.append(time.perf_counter() - t0)
+                out[name]["cpu_oracle_ms_per_call"] = round(statistics.median(ts) * 1e3, 1)
+            out["cpu_threads"] = torch.get_num_threads()
+        finally:
+            torch.set_num_threads(saved)
     return out
 
 

@@ -273,6 +273,13 @@ __device__ __forceinline__ float row16_max(float v) {
     v = dpp_max_f32<0x140>(v);  // row_mirror
     return v;
 }
+// max over the 8 lanes of each half of a 16-lane row (two 8-row neighbourhoods in one p-chunk: nsample = 8)
+__device__ __forceinline__ float row8_max(float v) {
+    v = dpp_max_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_max_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_max_f32<0x141>(v);  // row_half_mirror: lane i <-> 7 - i inside each half
+    return v;
+}
 // Max over the 16 points of a TRANSPOSED accumulator fragment.  Calling the MFMA with the operands swapped - activations as A,
 // weights as B (the per-lane fragments are the same registers either way) - gives D^T: lane = channel 16 n + (lane & 15), the four
 // registers x four lane groups = the 16 points.  The max over the points is then 3 in-lane max + two permlane swaps (7 instructions

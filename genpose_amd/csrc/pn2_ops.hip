@@ -24,6 +24,8 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // order-preserving float -> uint (total order on non-NaN floats)
 __device__ __forceinline__ uint32_t fkey(float f) {
     uint32_t u = __float_as_uint(f);
@@ -121,22 +123,39 @@ __device__ void fps_pass(int n, int m, lds_cptr sx, lds_cptr sy, lds_cptr sz, fl
     if (tid == 0) idx_out[0] = 0;
     for (int it = 1; it < m; ++it) {
         float x1 = sx[old], y1 = sy[old], z1 = sz[old];
-        uint32_t bd = 0u, br = 0u;  // thread-local best (distance key, rank); valid keys are >= 0x80000000
+        // thread-local best (distance bits, rank).  Squared distances and the running minimum are >= +0 (finite clouds: never NaN), where the
+        // unsigned order of the bit patterns IS the float order: the loop compares raw bits, and the order-preserving key of fkey() - for
+        // non-negative floats just the sign bit set - is applied once, to the thread's winner (valid keys are >= 0x80000000)
+        uint32_t bd = 0u, br = 0u;
+        float dist[PPT];
+        if constexpr (PPT % 2 == 0) {
+            // two points per instruction on the packed-f32 VALU (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE operations, in the same
+            // order, as sqdist's fmaf chain - identical bits)
+            const f32x2 X1 = {x1, x1}, Y1 = {y1, y1}, Z1 = {z1, z1};
+#pragma unroll
+            for (int j = 0; j < PPT; j += 2) {
+                const f32x2 dx = f32x2{px[j], px[j + 1]} - X1, dy = f32x2{py[j], py[j + 1]} - Y1, dz = f32x2{pz[j], pz[j + 1]} - Z1;
+                const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                dist[j] = d.x, dist[j + 1] = d.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) dist[j] = sqdist(px[j], py[j], pz[j], x1, y1, z1);
+        }
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             int k = tid + j * FPS_T;
             if (FULL || k < n) {
-                const float d = sqdist(px[j], py[j], pz[j], x1, y1, z1);
-                // fminf(d, tmp) on the bit patterns: squared distances and the running minimum are >= 0 (finite clouds: never NaN),
-                // where the unsigned order of the bits IS the float order - one v_min_u32 instead of canonicalise + v_min_f32
-                const uint32_t du = __float_as_uint(d), tu = __float_as_uint(tmp[j]);
-                tmp[j] = __uint_as_float(du < tu ? du : tu);
-                const uint32_t dk = fkey(tmp[j]);
+                // fminf(d, tmp) on the bit patterns: one v_min_u32 instead of canonicalise + v_min_f32
+                const uint32_t du = __float_as_uint(dist[j]), tu = __float_as_uint(tmp[j]);
+                const uint32_t dk = du < tu ? du : tu;
+                tmp[j] = __uint_as_float(dk);
                 const bool better = dk > bd || (dk == bd && rnk[j] > br);
                 bd = better ? dk : bd;
                 br = better ? rnk[j] : br;
             }
         }
+        bd |= 0x80000000u;
         const unsigned long long best = wave_max_key(bd, br);
         const int par = it & 1;
         if ((tid & 63) == 0) slots[par][tid >> 6] = best;
@@ -283,7 +302,10 @@ __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
 
 // ---------------------------------------------------------------------------------------------- ball query
 constexpr int BQ_T = 256;
-constexpr int BQ_CPW = 4;  // centres per wave
+// centres per wave.  Measured at 320 clouds (round 4): 8 / 16 centres per wave (fewer, longer workgroups that amortise the staging of the
+// cloud) cost +25 %; two centres in flight per wave (shared candidate reads, independent ballot chains) +5 %: the kernel is bound by its
+// many short waves' scalar chains, and more, shorter waves schedule best
+constexpr int BQ_CPW = 4;
 
 // One wave scans the cloud in index order, 64 candidates per step.  NS = number of scales (1 or 2).
 template <int NS, bool ZERO_FILL>

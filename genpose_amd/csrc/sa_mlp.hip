@@ -27,7 +27,8 @@ __device__ __forceinline__ void layer3_max(const SAArgs &a, const float *A, int 
     const int wn = wave % WN, wp = wave / WN;
     const int KG = c2p / 16, NC = gp_round16(a.c3) / 16;
     const int pc0 = wp * PT;
-    const int G = a.groupall ? PT : a.ns / 16;  // p-chunks per centre
+    const int G = a.groupall ? PT : (a.ns >= 16 ? a.ns / 16 : 1);  // p-chunks per centre (nsample = 8: two centres per p-chunk)
+    const bool half = !a.groupall && a.ns == 8;
     float *outb = a.out + (size_t)b * a.np * a.cout_total + a.cout_off;
     for (int ncb = wn; ncb < NC; ncb += WN * 4) {
         int nc[4], nv = 0;
@@ -51,7 +52,19 @@ __device__ __forceinline__ void layer3_max(const SAArgs &a, const float *A, int 
                 m.y = fmaxf(m.y, v.y);
                 m.z = fmaxf(m.z, v.z);
                 m.w = fmaxf(m.w, v.w);
-                if ((p + 1) % G == 0) {
+                if (half) {
+                    // nsample = 8 (ClsMSG_CFG_Dense level 2, ClsMSG_CFG_Lighter level 3; pointnet2.py:47-78): rows 0-7 and 8-15 of the
+                    // p-chunk are two neighbourhoods - pooled over the eight lanes of each half row, lanes 0 and 8 store
+                    m.x = row8_max(m.x);
+                    m.y = row8_max(m.y);
+                    m.z = row8_max(m.z);
+                    m.w = row8_max(m.w);
+                    if ((lane & 7) == 0 && ch < a.c3) {
+                        const int centre = (row0 + (pc0 + p) * 16) / 8 + ((lane >> 3) & 1);
+                        if (centre < a.np) *reinterpret_cast<f32x4 *>(outb + (size_t)centre * a.cout_total + ch) = m;
+                    }
+                    m = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else if ((p + 1) % G == 0) {
                     m.x = row16_max(m.x);
                     m.y = row16_max(m.y);
                     m.z = row16_max(m.z);
@@ -736,6 +749,8 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
     f32x4 *w2l = reinterpret_cast<f32x4 *>(lds);   // [Q1][Q2][64] resident
     f32x4 *ring = w2l + Q1 * Q2 * 64;               // [3][Q3][64]
     f32x4 *w1l = ring + 3 * SLICE;                  // [C1] rows (wx, wy, wz, b1)
+    float *b2l = reinterpret_cast<float *>(w1l + C1);  // [16 Q2] layer-2 bias, [C3] layer-3 bias: read where they are used, from LDS -
+    float *b3l = b2l + 16 * Q2;                         // a global read there waits (in-order vmcnt) for every operand request in flight
     const int tid = threadIdx.x, lane = tid & 63, pt = lane & 15, g = lane >> 4;
     for (int e = tid; e < Q1 * Q2 * 64; e += NTH) w2l[e] = reinterpret_cast<const f32x4 *>(a.w2)[e];
     for (int e = tid; e < C1; e += NTH) {
@@ -743,6 +758,8 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
         w.w = a.b1[e];
         w1l[e] = w;
     }
+    for (int e = tid; e < 16 * Q2; e += NTH) b2l[e] = a.b2[e];
+    for (int e = tid; e < C3; e += NTH) b3l[e] = a.b3[e];
     const f32x4 *w3g = reinterpret_cast<const f32x4 *>(a.w3);  // [Q2][Q3][64]: slice q = w3g + q*SLICE
     // ring prologue: slices 0 and 1 into slots 0 and 1; slice 2 held in registers
     f32x4 hold[PER_T];
@@ -782,7 +799,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
     };
     // register budget (256 at two waves per SIMD): the operands of the NEXT chunk are requested into the same registers
     // right after layer 1 has consumed the current ones (the ~40 k cycles of layers 2-3 cover the latency); biases are
-    // re-read from L1/L2 where they are used; the running max of a two-chunk neighbourhood is one register per output chunk (`res`).
+    // re-read from LDS where they are used; the running max of a two-chunk neighbourhood is one register per output chunk (`res`).
     int jn;
     float dcur[3];
     f32x4 zcur[Q1];
@@ -832,7 +849,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (n0 + u < Q2) {
-                    f32x4 v = acc[u] + *reinterpret_cast<const f32x4 *>(a.b2 + 16 * (n0 + u) + 4 * (lo >> 4));
+                    f32x4 v = acc[u] + *reinterpret_cast<const f32x4 *>(b2l + 16 * (n0 + u) + 4 * (lo >> 4));
                     h2[n0 + u] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
                 }
         }
@@ -880,7 +897,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
             for (int n = 0; n < Q3; ++n) {
                 const float m = points16_max_t(acc3[n]);
                 res[n] = p == 0 ? m : fmaxf(res[n], m);  // running max over the neighbourhood's chunks: one register per chunk
-                if (p == PT - 1 && g == 0 && it < nits) o[16 * n + pt] = fmaxf(res[n] + a.b3[16 * n + (lo & 15)], 0.f);
+                if (p == PT - 1 && g == 0 && it < nits) o[16 * n + pt] = fmaxf(res[n] + b3l[16 * n + (lo & 15)], 0.f);
             }
         }
     }
@@ -1095,7 +1112,7 @@ int launch_groupall_ring(const SAPreArgs &a, int b, hipStream_t st) {
 template <int C1, int C2, int C3, int NS, bool SPREAD>
 int launch_chain_ring(const SAPreArgs &a, int b, hipStream_t st) {
     constexpr int Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16;
-    const size_t lds = ((size_t)(Q1 * Q2 + 3 * Q3) * 64 + C1) * sizeof(f32x4);
+    const size_t lds = ((size_t)(Q1 * Q2 + 3 * Q3) * 64 + C1) * sizeof(f32x4) + (size_t)(16 * Q2 + C3) * sizeof(float);
     if (lds > 160 * 1024) return GP_EINVAL;
     auto kern = sa_chain_ring_kernel<C1, C2, C3, NS, SPREAD>;
     static bool done = false;
@@ -1155,7 +1172,7 @@ int gp_sa_mlp_max(int b, int n, int np, int ns, int cin, int c1, int c2, int c3,
     if (cout_off + c3 > cout_total) return GP_EINVAL;
     const bool groupall = (idx == nullptr);
     if (groupall && (np != 1 || new_xyz != nullptr || ns != n)) return GP_EINVAL;
-    if (!groupall && (!new_xyz || (ns % 16) != 0)) return GP_EINVAL;
+    if (!groupall && (!new_xyz || ((ns % 16) != 0 && ns != 8))) return GP_EINVAL;
     if (b == 0) return GP_OK;
     SAArgs a{n, np, ns, cin, c1, c2, c3, xyz, feats_in, new_xyz, idx, wpack1, bias1, wpack2, bias2, wpack3, bias3, out, cout_total, cout_off,
              groupall ? 1 : 0};
@@ -1204,7 +1221,7 @@ int gp_sa_pre_mlp_max_layout(int hidden_layout, int b, int n, int np, int ns, in
     const bool groupall = !idx && !new_xyz;  // GroupAll level: one neighbourhood = all n points
     if (!groupall && (!idx || !new_xyz)) return GP_EINVAL;
     if (groupall && (np != 1 || ns != n)) return GP_EINVAL;
-    if (!groupall && ((ns % 16) != 0 || ns > 64)) return GP_EINVAL;
+    if (!groupall && (((ns % 16) != 0 && ns != 8) || ns > 64)) return GP_EINVAL;
     if ((cout_total & 3) || (cout_off & 3) || (c3 & 3) || cout_off + c3 > cout_total) return GP_EINVAL;
     if (z && ((zstride & 3) || (zoff & 3) || zoff + c1 > zstride)) return GP_EINVAL;
     if (b == 0) return GP_OK;
@@ -1236,6 +1253,7 @@ int gp_sa_pre_mlp_max_layout(int hidden_layout, int b, int n, int np, int ns, in
     if (z && (zoff % 4) == 0 && (zstride % 4) == 0) {
         if (c1 == 64 && c2 == 64 && c3 == 128 && ns == 16) return launch_chain_lds<64, 64, 128, 16>(a, b, (hipStream_t)s);
         if (c1 == 64 && c2 == 96 && c3 == 128 && ns == 32) return launch_chain_lds<64, 96, 128, 32>(a, b, (hipStream_t)s);
+        if (c1 == 64 && c2 == 64 && c3 == 128 && ns == 32) return launch_chain_lds<64, 64, 128, 32>(a, b, (hipStream_t)s);  // ClsMSG_CFG_Lighter level 1
         const bool spread = hidden_layout == GP_SA_TAIL_SPREAD;
         if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 16)
             return spread ? launch_chain_ring<128, 196, 256, 16, true>(a, b, (hipStream_t)s) : launch_chain_ring<128, 196, 256, 16, false>(a, b, (hipStream_t)s);

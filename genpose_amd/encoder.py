@@ -88,8 +88,8 @@ class Pointnet2EncoderHIP:
                 cur = ws["new_xyz"][l]
         return xyz0
 
-    def _ball_queries(self, ws, xyz0, B, N):
-        """Ball queries of every grouping level (they depend on the coordinates only) into ws['bq']."""
+    def _ball_queries(self, ws, xyz0, B, N, levels=None):
+        """Ball queries of every grouping level (they depend on the coordinates only) into ws['bq']; `levels`: only those levels."""
         ws["_gen"] = next(_GENERATION)  # every writer of the grouping buffers invalidates outstanding tickets
         st = stream_ptr()
         cfg = self.cfg
@@ -98,6 +98,9 @@ class Pointnet2EncoderHIP:
             if npnt is None:
                 break
             new_xyz = ws["new_xyz"][k]
+            if levels is not None and k not in levels:
+                xyz, n = new_xyz, npnt
+                continue
             radii, nss = cfg["radii"][k], cfg["nsamples"][k]
             if len(self.w.levels[k]) == 2:
                 _lib.call("gp_ball_query_msg", B, n, npnt, float(radii[0]), nss[0], float(radii[1]), nss[1], ptr(new_xyz), ptr(xyz),
@@ -113,14 +116,56 @@ class Pointnet2EncoderHIP:
         c = self.cfg
         return (tuple(c["npoints"]), tuple(map(tuple, c["radii"])), tuple(map(tuple, c["nsamples"])))
 
-    def prepare_grouping(self, pts, slot=0):
+    def prepare_grouping(self, pts, slot=0, defer_join=False):
         """Furthest point sampling + gather + ball queries for every level into workspace `slot`; returns that workspace.  These
         depend on the point coordinates only - not on any weight - so a second encoder with the same grouping configuration (the
-        energy model's, which sees the same clouds) can take them over: forward(pts, grouping=<this workspace>)."""
-        xyz0 = self.sample_centres(pts, slot)
+        energy model's, which sees the same clouds) can take them over: forward(pts, grouping=<this workspace>).
+
+        defer_join (the encoder pass of an agent call): furthest point sampling is a chain of dependent block-wide argmax steps - 57 % of
+        them belong to level 0 - that occupies one wave per SIMD and no matrix pipe.  Only level 0 is sampled on the calling stream;
+        the deeper levels and their ball queries go to a side stream and run UNDERNEATH the level-0 set abstraction (ball query, both
+        chain kernels, the hoisted GEMM of level 1).  The workspace then carries the join event (`_join`), which forward(grouping=ws)
+        waits for before its first use of a deeper level."""
+        pending = self._workspace(pts.shape[0], pts.shape[1], slot).pop("_join", None)
+        if pending is not None:  # a deferred grouping nobody consumed: its side work must not race the writes below
+            torch.cuda.current_stream(self.device).wait_event(pending)
+        cfg = self.cfg
+        group_levels = [k for k, npnt in enumerate(cfg["npoints"]) if npnt is not None]
+        if not (defer_join and 2 <= len(group_levels) <= 3 and pts.shape[1] <= 1024 and pts.is_cuda):
+            xyz0 = self.sample_centres(pts, slot)
+            B, N, _ = xyz0.shape
+            ws = self._workspace(B, N, slot)
+            self._ball_queries(ws, xyz0, B, N)
+            ws["_grouping_key"] = self.grouping_key()
+            return ws
+        _lib.check_device()
+        if pts.dtype != torch.float32:
+            raise RuntimeError("pts must be a float32 CUDA tensor")
+        xyz0 = pts[..., 0:3].contiguous()
         B, N, _ = xyz0.shape
         ws = self._workspace(B, N, slot)
-        self._ball_queries(ws, xyz0, B, N)
+        ws["_gen"] = next(_GENERATION)
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        m0 = (ctypes.c_int * 3)(cfg["npoints"][group_levels[0]], 0, 0)
+        _lib.call("gp_fps_chain", B, N, 1, m0, ptr(xyz0), ptr(ws["fps_idx"][0]), ptr(ws["new_xyz"][0]), None, None, None, None, stream_ptr())
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(fork)
+            rest = group_levels[1:]
+            mr = (ctypes.c_int * 3)(*([cfg["npoints"][k] for k in rest] + [0] * (3 - len(rest))))
+            pi = [ptr(ws["fps_idx"][l + 1]) if l < len(rest) else None for l in range(2)]
+            px = [ptr(ws["new_xyz"][l + 1]) if l < len(rest) else None for l in range(2)]
+            # the deeper levels select among level 0's centres, in their order: the same chain, started from new_xyz[0]
+            _lib.call("gp_fps_chain", B, cfg["npoints"][group_levels[0]], len(rest), mr, ptr(ws["new_xyz"][0]), pi[0], px[0], pi[1], px[1], None, None,
+                      stream_ptr())
+            self._ball_queries(ws, xyz0, B, N, levels=set(rest))
+            join = torch.cuda.Event()
+            join.record(self._side)
+        self._ball_queries(ws, xyz0, B, N, levels={group_levels[0]})
+        ws["_join"] = join
         ws["_grouping_key"] = self.grouping_key()
         return ws
 
@@ -175,7 +220,7 @@ class Pointnet2EncoderHIP:
         return ent["out"].clone()
 
     def _forward_with_grouping(self, pts):
-        ws = self.prepare_grouping(pts)
+        ws = self.prepare_grouping(pts, defer_join=True)
         return self.forward(pts, grouping=ws), ws
 
     def forward(self, pts, return_intermediates=False, slot=0, centres_done=False, grouping=None):
@@ -229,6 +274,10 @@ class Pointnet2EncoderHIP:
             zstride = sum(sc.couts[0] for sc in scales)
             if z is not None:
                 _lib.call("gp_point_linear", B * n, cin, zstride, ptr(feats), ptr(self.w.z_weights[k]), ptr(z), st)
+            if k >= 1 and src.get("_join") is not None:
+                # deferred grouping (prepare_grouping(defer_join=True)): the deeper levels' centres and neighbourhoods were computed on
+                # the side stream under level 0 - first use here
+                torch.cuda.current_stream(self.device).wait_event(src.pop("_join"))
             off, zoff = 0, 0
             for i, sc in enumerate(scales):
                 (w1, b1), (w2, b2), (w3, b3) = sc.layers

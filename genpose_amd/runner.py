@@ -120,15 +120,16 @@ def add_noise_to_RT(RT, r=5.0, t=0.03, draws=None):
 
 
 class _FrameGraphs:
-    """hipGraphs of the two launch sequences of a tracking frame that need no host decision, keyed by the object count n:
-      A  clouds [n,1024,3] -> centres, both models' per-cloud embeddings: grouping (furthest point sampling, ball queries) once, the
-         score model's encoder, the energy model's encoder on the same centres and neighbourhoods, the two cloud embeddings
-         (~45 launches);
-      B  candidates [n,K,9] -> energies -> ranking -> top-`sel` aggregation -> 4x4 poses (energy evaluation, gp_rank_aggregate and
-         the small conversions).
-    Between them sits the adaptive ODE solve, whose attempts are graph replays of their own.  A 5-object frame is then A + the
+    """hipGraphs of the launch sequences of a tracking frame that need no host decision, keyed by the clouds' shape:
+      A   clouds [n,1024,3] -> centres, the SCORE model's per-cloud embedding: grouping (furthest point sampling with its deeper levels on a
+          side branch under level 0, ball queries) once, the score model's encoder, its cloud embedding;
+      A'  the ENERGY model's encoder on the same centres and neighbourhoods + its cloud embedding.  Nothing before the ranking needs it,
+          and the adaptive solve of a frame occupies 10-19 of the 256 CUs: A' is replayed on a side stream and runs UNDERNEATH the solve;
+      B   candidates [n,K,9] -> energies -> ranking -> top-`sel` aggregation -> 4x4 poses (energy evaluation, gp_rank_aggregate and
+          the small conversions); waits for A'.
+    Between A and B sits the adaptive ODE solve, whose attempts are graph replays of their own.  A 5-object frame is then A + the
     solve's replay(s) + B instead of ~70 individually launched kernels.  Inputs are copied into static buffers, outputs are static
-    tensors that the NEXT frame of the same object count overwrites (callers that keep them clone)."""
+    tensors that the NEXT frame of the same shape overwrites (callers that keep them clone)."""
 
     def __init__(self, snet, enet, K, sel, T_energy=1e-5):
         from .sde import SIGMA_MAX, SIGMA_MIN
@@ -138,32 +139,49 @@ class _FrameGraphs:
         self.tvec_e = enet.pose_score_net.time_embed(t)[0].contiguous()
         self.sigma_e = (SIGMA_MIN * (SIGMA_MAX / SIGMA_MIN) ** t).contiguous()
         self.share = snet.pts_encoder.grouping_key() == enet.pts_encoder.grouping_key()
+        self.side = torch.cuda.Stream(dev)
+        self.ev_a, self.ev_e = torch.cuda.Event(), torch.cuda.Event()
         self._a, self._b = {}, {}
 
     SLOT = "frame-graphs"  # the replays write into encoder workspaces of their own: no ticket of the agent path ever points at them
 
-    def _embed_body(self, pts):
-        enc_s, enc_e = self.snet.pts_encoder, self.enet.pts_encoder
-        grouping = enc_s.prepare_grouping(pts, slot=self.SLOT) if self.share else None
+    def _score_body(self, pts):
+        enc_s = self.snet.pts_encoder
+        # (deferred join: the deeper sampling levels run on a side branch of the graph underneath the level-0 set abstraction)
+        grouping = enc_s.prepare_grouping(pts, slot=self.SLOT, defer_join=True) if self.share else None
         cvec_s = self.snet.pose_score_net.cloud_embed(enc_s.forward(pts, slot=self.SLOT, grouping=grouping))
-        cvec_e = self.enet.pose_score_net.cloud_embed(enc_e.forward(pts, slot=self.SLOT, grouping=grouping))
-        return pts.mean(dim=1), cvec_s, cvec_e
+        return grouping, pts.mean(dim=1), cvec_s
+
+    def _energy_body(self, pts, grouping):
+        return self.enet.pose_score_net.cloud_embed(self.enet.pts_encoder.forward(pts, slot=self.SLOT, grouping=grouping))
 
     def embed(self, pts):
-        """-> (centre [n,3], cvec of the score model [n,768], cvec of the energy model [n,768])"""
+        """-> (centre [n,3], cvec of the score model [n,768], cvec of the energy model [n,768]); the energy model's embedding is still
+        being computed on the side stream when this returns - rank() waits for it."""
         key = (tuple(pts.shape), pts.dtype)
         ent = self._a.get(key)
+        cur = torch.cuda.current_stream(pts.device)
         if ent is None:
             buf = pts.clone()
-            self._embed_body(buf)  # warm-up outside capture: workspaces, kernel attributes
+            grouping, _, _ = self._score_body(buf)  # warm-up outside capture: workspaces, kernel attributes
+            self._energy_body(buf, grouping)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                outs = self._embed_body(buf)
-            ent = self._a[key] = (g, buf, outs)
-        g, buf, outs = ent
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                grouping, centre, cvec_s = self._score_body(buf)
+            ge = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ge, stream=self.side):
+                cvec_e = self._energy_body(buf, grouping)
+            ent = self._a[key] = (ga, ge, buf, (centre, cvec_s, cvec_e))
+        ga, ge, buf, outs = ent
+        cur.wait_event(self.ev_e)  # the previous frame's A' (side stream) has finished reading `buf`, which is about to change
         buf.copy_(pts)
-        g.replay()
+        ga.replay()
+        self.ev_a.record(cur)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_a)
+            ge.replay()
+            self.ev_e.record(self.side)
         return outs
 
     def _rank_body(self, pred, centre, cvec_e):
@@ -178,6 +196,7 @@ class _FrameGraphs:
         """pred [n,K,9] f64 -> (energy [n,K,2], sorted_RTs [n,K,4,4], average_sRT [n,4,4])"""
         key = (tuple(pred.shape), pred.dtype)
         ent = self._b.get(key)
+        torch.cuda.current_stream(pred.device).wait_event(self.ev_e)  # the energy model's embedding (side stream, under the solve)
         if ent is None:
             bufs = (pred.clone(), centre.clone(), cvec_e.clone())
             self._rank_body(*bufs)

@@ -25,16 +25,22 @@ def mlp_specs(mlps=LIGHT_MLPS, input_channels=0):
     return out
 
 
-def make_state_dict(seed=0, mode="score"):
+def make_state_dict(seed=0, mode="score", params="light"):
     """Random weights with the reference's shapes and key names; output layers (zero-initialised by the
-    reference, scorenet.py:156-170) re-drawn N(0,0.05), BN statistics randomised so BN folding is exercised."""
+    reference, scorenet.py:156-170) re-drawn N(0,0.05), BN statistics randomised so BN folding is exercised.
+    params: the encoder configuration (--pointnet2_params: 'light' | 'dense' | 'lighter', pointnet2.py:47-78)."""
     g = torch.Generator().manual_seed(seed + (0 if mode == "score" else 7919))
     sd = {}
 
     def rn(*shape, std=1.0):
         return torch.randn(*shape, generator=g) * std
 
-    for (k, i, spec) in mlp_specs():
+    if params == "light":
+        mlps = LIGHT_MLPS
+    else:
+        from .weights import ENCODER_CFGS
+        mlps = ENCODER_CFGS[params]["mlps"]
+    for (k, i, spec) in mlp_specs(mlps):
         for l in range(3):
             cin, cout = spec[l], spec[l + 1]
             p = f"pts_encoder.SA_modules.{k}.mlps.{i}.layer{l}."

@@ -20,6 +20,7 @@ What each file pins:
   g10..g13        mAP evaluation, depth -> cloud pre-processing, likelihood, score of the energy model (--g10 .. --g13).
   g14_train_step.npz  one training step of the score model (--g14): loss, clipped gradients, Adam update, EMA, BN statistics.
   g15_energy_train_step.npz  one training step of the energy model incl. the ranking loss (--g15).
+  g16_encoder_{dense,lighter}.npz  the encoder under the reference's other configurations (--g16 dense | --g16 lighter; one process each).
 """
 import hashlib
 import os
@@ -548,7 +549,44 @@ def main_g15():
     print("g15_energy_train_step.npz", os.path.getsize(os.path.join(OUT, "g15_energy_train_step.npz")), "gf", g15["loss_gf"], "ranking", g15["loss_ranking"])
 
 
+def main_g16(params):
+    """G16: the encoder under the reference's OTHER configurations (--pointnet2_params dense | lighter, pointnet2.py:47-78; the reference
+    picks the configuration when networks/pts_encoder/pointnet2.py is imported, so every configuration is its own process):
+    Pointnet2ClsMSG(0) forward on the four golden clouds, per-level features of cloud 0."""
+    from genpose_amd.weights import ENCODER_CFGS
+    from genpose_amd.weights_synth import make_state_dict
+    os.makedirs(OUT, exist_ok=True)
+    ns = ref_import.load(extra_argv=("--pointnet2_params", params))
+    torch.set_grad_enabled(False)
+    import argparse
+    cfg = argparse.Namespace(**vars(ns.cfg))
+    assert cfg.pointnet2_params == params
+    cfg.posenet_mode, cfg.sampler_mode, cfg.sampling_steps = "score", ["ode"], None
+    agent = ns.PoseNet(cfg)
+    agent.net.load_state_dict(make_state_dict(0, "score", params), strict=True)
+    agent.net.eval()
+    clouds = synth.golden_clouds()
+    xyz = torch.from_numpy(clouds)
+    feat = agent.net({"pts": xyz}, mode="pts_feature")
+    inter = []
+    hooks = [m.register_forward_hook(lambda m, i, o: inter.append(o)) for m in agent.net.pts_encoder.SA_modules]
+    agent.net({"pts": xyz[:1]}, mode="pts_feature")
+    for h in hooks:
+        h.remove()
+    g = {"clouds": clouds, "feat": feat.numpy(), "seed": np.array(0), "params": np.array(params)}
+    nlev = sum(1 for n in ENCODER_CFGS[params]["npoints"] if n is not None)
+    assert len(inter) == nlev + 1
+    for lvl in range(nlev):
+        nx, f = inter[lvl]
+        g[f"new_xyz{lvl}"] = nx[0].numpy()
+        g[f"feat{lvl}_first32"] = f[0, :, :32].numpy()  # [C, 32 points]
+    np.savez_compressed(os.path.join(OUT, f"g16_encoder_{params}.npz"), **g)
+    print("wrote", f"g16_encoder_{params}.npz", feat.shape, float(feat.abs().mean()))
+
+
 if __name__ == "__main__":
+    if "--g16" in sys.argv:
+        sys.exit(main_g16(sys.argv[sys.argv.index("--g16") + 1]))
     if "--g15" in sys.argv:
         sys.exit(main_g15())
     if "--g14" in sys.argv:

@@ -117,7 +117,7 @@ def test_2048_cloud_batch_coupled_over_eight_ranks_equals_the_unsharded_batch(sh
     clouds, got = sharded
     sp, ep = _agents("pc", NSTEPS)
     want = {k: v.cpu().numpy() for k, v in _coupled_pc(sp, ep, range(WORLD), None)(clouds).items()}
-    assert sp.net.last_sampler.kernel_name == "pc_step_chain_kernel<2>"  # one 102 400-row batch: the chain form; the shards ran 32-row tiles
+    assert sp.net.last_sampler.R == NCL * K and sp.net.last_sampler.groups == 1  # ONE 102 400-row batch with one batch-global statistic
     pred, ref = got["c_pred_pose"], want["pred_pose"]
     assert pred.shape == ref.shape == (NCL, K, 9) and np.isfinite(pred).all()
     rot = np.abs(pred[..., :6] - ref[..., :6])

@@ -106,3 +106,42 @@ def test_grouping_ticket_dies_with_the_workspace_contents():
     assert not enc_e.ticket_valid(data["_grouping"], pts, enc_e.grouping_key())
     data = ticketed()
     assert not enc_e.ticket_valid(data["_grouping"], pts.clone(), enc_e.grouping_key())
+
+
+@pytest.mark.parametrize("params", ["dense", "lighter"])
+def test_other_encoder_configurations(golden, params):
+    """--pointnet2_params dense | lighter (pointnet2.py:47-78): neighbourhoods of 8 and 64 samples, four single-scale grouping levels and
+    a 512 -> 512 -> 1024 GroupAll level.  Against the fixture captured from the imported reference (G16), then against the oracle at 5 and
+    64 clouds with bit-exact centres and neighbourhoods on every level; and through the agent (`cfg.pointnet2_params`)."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.encoder import Pointnet2EncoderHIP
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.weights import ENCODER_CFGS
+    cfg = ENCODER_CFGS[params]
+    nlev = sum(1 for n in cfg["npoints"] if n is not None)
+    sd = go.make_state_dict(0, "score", params)
+    enc = Pointnet2EncoderHIP(sd, "cuda", params)
+    g = golden(f"g16_encoder_{params}.npz")
+    feat, ws = enc.forward(torch.from_numpy(g["clouds"]).cuda(), return_intermediates=True)
+    for lvl in range(nlev):
+        assert np.array_equal(ws["new_xyz"][lvl][0].cpu().numpy(), g[f"new_xyz{lvl}"])
+        mine = ws["feat"][lvl][0].cpu().numpy()[:32].T
+        np.testing.assert_allclose(mine, g[f"feat{lvl}_first32"], rtol=ENC_RTOL, atol=ENC_ATOL, err_msg=f"{params} level {lvl}")
+    np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], rtol=ENC_RTOL, atol=ENC_ATOL)
+    for B, start in [(5, 300), (64, 1300)]:
+        pts = synth.make_batch(B, start)
+        got, ws = enc.forward(torch.from_numpy(pts).cuda(), return_intermediates=True)
+        got = got.cpu().numpy()
+        for s in range(0, B, 16):
+            ref, inter = go.encoder_forward(sd, torch.from_numpy(pts[s:s + 16]), cfg=cfg, return_intermediates=True)
+            np.testing.assert_allclose(got[s:s + 16], ref.numpy(), rtol=ENC_RTOL, atol=ENC_ATOL, err_msg=f"{params} B={B} clouds {s}..")
+            for lvl in range(nlev):
+                assert np.array_equal(ws["fps_idx"][lvl][s:s + 16].cpu().numpy(), inter[lvl]["fps_idx"]), (params, B, lvl)
+                for i in range(len(cfg["radii"][lvl])):
+                    assert np.array_equal(ws["bq"][lvl][i][s:s + 16].cpu().numpy(), inter[lvl][f"bq_idx{i}"]), (params, B, lvl, i)
+    agent = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"], pointnet2_params=params))
+    agent.load_state_dict(sd)
+    pts = torch.from_numpy(synth.make_batch(3, 40)).cuda()
+    pred = agent.pred_func({"pts": pts, "pts_center": pts.mean(dim=1)}, repeat_num=4, save_path=None, T0=0.3)
+    assert pred.shape == (3, 4, 9) and torch.isfinite(pred).all()

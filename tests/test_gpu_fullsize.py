@@ -394,3 +394,53 @@ def test_drop_in_eval_single_as_timed():
     a = avg[sl].cpu().numpy()
     np.testing.assert_allclose(a[:, 4:], qt.numpy()[:, 4:], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(qt.numpy()[:, 4:]).max())))
     assert np.all(np.abs(np.sum(a[:, :4] * qt.numpy()[:, :4], axis=1)) > 1 - 1e-5)
+
+
+@pytest.mark.parametrize("sampler,steps,T0", [("pc", 20, None), ("ode", None, 0.55)])
+def test_config0_single_object(sampler, steps, T0):
+    """BASELINE configs[0] - the reference's own CPU-runnable case: ONE cloud of 1024 points, 10 candidates, 20 SDE steps (PC) or the
+    default adaptive ODE solve, through the agent (evaluation_single.py path) - against the oracle end to end: encoder, sampler, energies,
+    ranking, aggregation.  Second and third calls (the captured encoder pass, its replay) give the first call's bits."""
+    from genpose_amd import reward, synth
+    B, K = 1, 10
+    sa, ea = make_agent("score", sampler, steps), make_agent("energy")
+    pts_np = synth.make_batch(B, start=4242)
+    pts = torch.from_numpy(pts_np).cuda()
+    gen = torch.Generator().manual_seed(8)
+    prior = torch.randn(B * K, 9, generator=gen)
+    noise_cpu = (torch.randn(steps, B * K, 9, generator=gen), torch.randn(steps, B * K, 9, generator=gen)) if sampler == "pc" else None
+    noise = None if noise_cpu is None else tuple(z.cuda() for z in noise_cpu)
+    sa.net.prior_fn = lambda shape, T=1.0: prior * (0.01 * 5000.0 ** T)
+    outs = []
+    for _ in range(3):
+        data = {"pts": pts, "pts_center": pts.mean(dim=1)}
+        pred = sa.pred_func(data, repeat_num=K, save_path=None, T0=T0, noise=noise)
+        energy = ea.get_energy(data=data, pose_samples=pred, T=1e-5)
+        r = reward.rank_aggregate(pred, energy, ratio=0.6)
+        outs.append((pred.clone(), energy.clone(), r["order"].clone(), r["avg_pose"].clone()))
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+    pred, energy, order, avg = outs[0]
+    sd, sde = go.make_state_dict(0, "score"), go.make_state_dict(0, "energy")
+    pts_cpu = torch.from_numpy(pts_np)
+    cen = pts_cpu.mean(dim=1)
+    if sampler == "pc":
+        ref, _, _ = go.pred_func(sd, pts_cpu, cen, K, "pc", prior, sampling_steps=steps, z_langevin=noise_cpu[0], z_predictor=noise_cpu[1])
+        np.testing.assert_allclose(pred.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-3)
+    else:
+        ref, _, nfev = go.pred_func(sd, pts_cpu, cen, K, "ode", prior, T0=T0)
+        assert abs(int(sa.net.last_sampler.last_stats["nfev"]) - nfev) <= 6
+        got = pred.cpu().numpy()
+        np.testing.assert_allclose(got[..., :6], ref.numpy()[..., :6], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(got[..., 6:], ref.numpy()[..., 6:], rtol=0, atol=5e-4 * max(1.0, float(ref[..., 6:].abs().max())))
+    ref_e = go.get_energy(sde, pts_cpu, cen, pred.cpu(), T=1e-5).numpy()
+    np.testing.assert_allclose(energy.cpu().numpy(), ref_e, rtol=5e-4, atol=5e-4 * np.abs(ref_e).max())
+    e_cpu = energy.cpu()
+    for c in range(2):
+        assert torch.equal(order[:, :, c].cpu().long(), torch.sort(e_cpu[:, :, c], dim=1, descending=True, stable=True).indices)
+    sorted_poses = reward.rank_aggregate(pred, energy, ratio=0.6)["sorted_poses"]
+    _, qt = go.aggregate_sorted(go.pose9_to_RT(sorted_poses.cpu()), ratio=0.6)
+    a = avg.cpu().numpy()
+    np.testing.assert_allclose(a[:, 4:], qt.numpy()[:, 4:], rtol=1e-5, atol=1e-5)
+    assert np.all(np.abs(np.sum(a[:, :4] * qt.numpy()[:, :4], axis=1)) > 1 - 1e-5)

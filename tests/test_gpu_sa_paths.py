@@ -73,12 +73,55 @@ def test_unsupported_shapes_fail_loudly():
     from genpose_amd import _lib
     from genpose_amd._lib import ptr, stream_ptr
     x = torch.zeros(1, 64, 3, device="cuda")
-    idx = torch.zeros(1, 8, 8, dtype=torch.int32, device="cuda")
+    idx = torch.zeros(1, 8, 24, dtype=torch.int32, device="cuda")
     w = torch.zeros(4096, device="cuda")
     out = torch.zeros(1, 8, 32, device="cuda")
-    with pytest.raises(_lib.GenposeHipError):  # nsample 8 (the reference's 'dense' config, level 2) is not a multiple of 16
-        _lib.call("gp_sa_mlp_max", 1, 64, 8, 8, 0, 16, 16, 32, ptr(x), None, ptr(x), ptr(idx), ptr(w), ptr(w), ptr(w), ptr(w), ptr(w), ptr(w),
+    with pytest.raises(_lib.GenposeHipError):  # neighbourhoods are 8 samples or a multiple of 16 (every configuration of pointnet2.py:24-78)
+        _lib.call("gp_sa_mlp_max", 1, 64, 8, 24, 0, 16, 16, 32, ptr(x), None, ptr(x), ptr(idx), ptr(w), ptr(w), ptr(w), ptr(w), ptr(w), ptr(w),
                   ptr(out), 32, 0, stream_ptr())
+
+
+@pytest.mark.parametrize("ns", [8, 64])
+def test_small_and_large_neighbourhoods_vs_oracle(ns):
+    """nsample = 8 (two neighbourhoods per 16-row MFMA chunk, pooled over half rows) and 64, un-hoisted and hoisted tile kernels against
+    the oracle's grouped shared MLP + max-pool, with input features."""
+    from genpose_amd import _lib
+    from genpose_amd._lib import ptr, stream_ptr
+    from genpose_amd.weights import SAScale
+    from oracle import pn2_oracle as ops
+    B, n, npnt, cin, spec = 3, 200, 37, 32, [48, 80, 64]
+    gen = torch.Generator().manual_seed(ns)
+    xyz = torch.rand(B, n, 3, generator=gen) * 0.2
+    feats = torch.randn(B, n, cin, generator=gen)
+    new_xyz = xyz[:, :npnt].contiguous()
+    bq = ops.ball_query(0.08, ns, xyz.numpy(), new_xyz.numpy())
+    sd = {}
+    chans = [cin + 3] + spec
+    for l in range(3):
+        p = f"m.layer{l}."
+        sd[p + "conv.weight"] = torch.randn(chans[l + 1], chans[l], 1, 1, generator=gen) * (2.0 / chans[l]) ** 0.5
+        sd[p + "bn.bn.weight"] = 1.0 + 0.1 * torch.randn(chans[l + 1], generator=gen)
+        sd[p + "bn.bn.bias"] = 0.1 * torch.randn(chans[l + 1], generator=gen)
+        sd[p + "bn.bn.running_mean"] = 0.1 * torch.randn(chans[l + 1], generator=gen)
+        sd[p + "bn.bn.running_var"] = (1.0 + 0.1 * torch.randn(chans[l + 1], generator=gen)).abs() + 0.05
+    g_xyz = torch.from_numpy(ops.group_points(np.ascontiguousarray(xyz.numpy().transpose(0, 2, 1)), bq)) - new_xyz.transpose(1, 2).unsqueeze(-1)
+    g_f = torch.from_numpy(ops.group_points(np.ascontiguousarray(feats.numpy().transpose(0, 2, 1)), bq))
+    ref = go._shared_mlp(sd, "m.", torch.cat([g_xyz, g_f], dim=1)).max(dim=3)[0].permute(0, 2, 1).numpy()  # [B, np, C]
+    sc = SAScale(sd, "m.", cin, "cuda")
+    (w1, b1), (w2, b2), (w3, b3) = sc.layers
+    xd, fd, nd, idx = xyz.cuda(), feats.cuda(), new_xyz.cuda(), torch.from_numpy(bq).cuda()
+    out_a = torch.zeros(B, npnt, spec[-1], device="cuda")
+    _lib.call("gp_sa_mlp_max", B, n, npnt, ns, cin, *spec, ptr(xd), ptr(fd), ptr(nd), ptr(idx), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3),
+              ptr(out_a), spec[-1], 0, stream_ptr())
+    from genpose_amd.weights import pack_weight
+    z = torch.empty(B, n, spec[0], device="cuda")
+    _lib.call("gp_point_linear", B * n, cin, spec[0], ptr(fd), ptr(pack_weight(sc.w1_feat).cuda()), ptr(z), stream_ptr())
+    out_b = torch.zeros(B, npnt, spec[-1], device="cuda")
+    _lib.call("gp_sa_pre_mlp_max_layout", sc.hidden_layout, B, n, npnt, ns, *spec, ptr(xd), ptr(nd), ptr(idx), ptr(z), spec[0], 0, ptr(sc.wxyz), ptr(b1),
+              ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out_b), spec[-1], 0, stream_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out_a.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out_b.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
 
 
 @pytest.mark.parametrize("k_in,n_out", [(96, 128), (256, 256), (512, 512), (64, 96)])

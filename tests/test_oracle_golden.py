@@ -62,6 +62,20 @@ def test_g3_encoder(golden, sd_score):
         np.testing.assert_allclose(inter[lvl]["features"][0][:, :32], g[f"feat{lvl}_first32"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("params", ["dense", "lighter"])
+def test_g16_encoder_other_configurations(golden, params):
+    """The reference's other encoder configurations (--pointnet2_params dense | lighter, pointnet2.py:47-78: nsample 8 / 64 neighbourhoods,
+    four single-scale grouping levels), captured from the imported reference, one process per configuration."""
+    from genpose_amd.weights import ENCODER_CFGS
+    g = golden(f"g16_encoder_{params}.npz")
+    cfg = ENCODER_CFGS[params]
+    feat, inter = go.encoder_forward(go.make_state_dict(0, "score", params), torch.from_numpy(g["clouds"]), cfg=cfg, return_intermediates=True)
+    np.testing.assert_allclose(feat.numpy(), g["feat"], rtol=1e-5, atol=1e-5)
+    for lvl in range(sum(1 for n in cfg["npoints"] if n is not None)):
+        np.testing.assert_array_equal(inter[lvl]["new_xyz"][0], g[f"new_xyz{lvl}"])
+        np.testing.assert_allclose(inter[lvl]["features"][0][:, :32], g[f"feat{lvl}_first32"], rtol=1e-5, atol=1e-5)
+
+
 def test_g4_g5_nets(golden, sd_score, sd_energy):
     g = golden("g4_g5_nets.npz")
     pf, pose = torch.from_numpy(g["pts_feat"]), torch.from_numpy(g["pose"])
