@@ -288,7 +288,7 @@ def main():
             side["ode_100"] = ode_leg(torch, B, K, G, T0, pool, str(dev))
             side["full_pipeline_256"] = full_pipeline_leg(torch, K, n, str(dev))
             side["drop_in_eval_single"] = drop_in_leg(torch, str(dev), K)
-            side["config0_single_object"] = config0_leg(torch, str(dev), cpu=not args.no_cpu_baseline)
+            side["config0_single_object"] = config0_leg(torch, str(dev))
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
@@ -639,10 +639,11 @@ def drop_in_leg(torch, dev, K, B=256, T0=0.55):
     return out
 
 
-def config0_leg(torch, dev, cpu=True):
+def config0_leg(torch, dev):
     """BASELINE configs[0] - the reference's own CPU-runnable case: ONE cloud x 1024 pts, 10 candidates, 20 SDE steps (PC) and the default
     adaptive ODE solve (T0 = 0.55), evaluation_single.py call sequence through the agent API: latency per call on the device (the work of a
-    call is far too small to fill the chip: this is a latency figure, not a throughput one), and the oracle on the host beside it."""
+    call is far too small to fill the chip: this is a latency figure, not a throughput one).  The oracle's time for the same call on the
+    host sits in `cpu_baseline.config0_single_object`."""
     from genpose_amd import reward, synth
     from genpose_amd.config import get_config
     from genpose_amd.posenet_agent import PoseNet
@@ -675,26 +676,6 @@ def config0_leg(torch, dev, cpu=True):
         out[name] = {"ms_per_call": round(dt * 1e3, 3), "poses_per_s": round(B / dt, 1)}
         if sampler == "ode":
             out[name]["nfev"] = int(sa.net.last_sampler.last_stats["nfev"])
-    if cpu:
-        from oracle import genpose_oracle as go
-        sd, sde = go.make_state_dict(0, "score"), go.make_state_dict(0, "energy")
-        pts = pool[0].cpu()
-        gen = torch.Generator().manual_seed(0)
-        prior, z1, z2 = torch.randn(K, 9, generator=gen), torch.randn(20, K, 9, generator=gen), torch.randn(20, K, 9, generator=gen)
-        saved = torch.get_num_threads()
-        torch.set_num_threads(min(8, os.cpu_count() or 1))
-        try:
-            for name, smp, kw in (("pc_20", "pc", dict(sampling_steps=20, z_langevin=z1, z_predictor=z2)), ("ode_T0_0.55", "ode", dict(T0=0.55))):
-                ts = []
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    pred, _, _ = go.pred_func(sd, pts, pts.mean(dim=1), K, smp, prior, **kw)
-                    go.get_energy(sde, pts, pts.mean(dim=1), pred, T=1e-5)
-                    ts.append(time.perf_counter() - t0)
-                out[name]["cpu_oracle_ms_per_call"] = round(statistics.median(ts) * 1e3, 1)
-            out["cpu_threads"] = torch.get_num_threads()
-        finally:
-            torch.set_num_threads(saved)
     return out
 
 
@@ -766,10 +747,26 @@ def run_cpu_baseline(torch, args, K, n):
             runs.append(time.perf_counter() - t0)
             if time.perf_counter() - t_start + runs[-1] > budget or len(runs) >= 10:
                 break
+        # BASELINE configs[0] (one cloud, 10 candidates, 20 PC steps / the default ODE solve + energies) on the host: the oracle's latency
+        # per call beside the device's `config0_single_object` figures (a fraction of a second of CPU work)
+        set_threads(min(8, ncores))
+        p1 = torch.from_numpy(synth.make_batch(1, start=30000))
+        sde_ = go.make_state_dict(0, "energy")
+        c0 = {"threads": min(8, ncores)}
+        for name, smp, kw in (("pc_20", "pc", dict(sampling_steps=20, z_langevin=torch.randn(20, 10, 9, generator=gen), z_predictor=torch.randn(20, 10, 9, generator=gen))),
+                              ("ode_T0_0.55", "ode", dict(T0=0.55))):
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pred1, _, _ = go.pred_func(sd, p1, p1.mean(dim=1), 10, smp, prior[:10], **kw)
+                go.get_energy(sde_, p1, p1.mean(dim=1), pred1, T=1e-5)
+                ts.append(time.perf_counter() - t0)
+            c0[name + "_ms_per_call"] = round(statistics.median(ts) * 1e3, 1)
     finally:
         set_threads(saved)
     med = statistics.median(runs)
     return {"value": round(Bc / med, 3), "unit": "poses/s", "cores": max(best_enc, best_smp), "kind": "port", "host_cores": ncores,
+            "config0_single_object": c0,
             "threads": {"encoder": best_enc, "sampler": best_smp},
             "encoder_s_by_threads": {t: round(v, 3) for t, v in enc_s.items()}, "sampler_s_by_threads": {t: round(v, 3) for t, v in smp_s.items()},
             "end_to_end_runs_s": [round(r, 2) for r in runs],
