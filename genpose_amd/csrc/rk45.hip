@@ -10,7 +10,7 @@
 // The error norm is the reference's batch-global RMS over all R*9 components: per-tile partial sums, reduced in
 // a fixed order by the single-workgroup decide kernel (deterministic).
 #include "score_bwd.h"
-#include "trunk_chain.h"
+#include "trunk_chain_vjp.h"
 
 namespace {
 
@@ -232,33 +232,43 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
 // The same stage in the CHAIN form of the trunk (trunk_chain.h; score model, equal groups, launches of ~32 000 rows and more): a wave
 // carries 16 * PT rows from the stage input to K_s in registers.  Lane (row, g) owns components 4g .. 4g+3 of its row - exactly the
 // B fragment of the first layer - so the f64 stage arithmetic is spread over all lanes with no exchange.
-template <int PT, int STAGE>
+// MODEL 1 / 2 (the energy model's score, the likelihood ODE): forward + vector-Jacobian chain of trunk_chain_vjp.h.  With ten state
+// components per row (model 2) lane group 2 owns components 8 and 9 - the pose's last one and the log-density, which is no network input.
+template <int PT, int STAGE, int MODEL>
 __global__ __launch_bounds__(gp_chain::NT, 1) void rk45_stage_chain_kernel(OdeArgs a, gp_scorenet net) {
     using C = gp_chain::Cfg<PT>;
+    constexpr int NC = OdeModel<MODEL>::NC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double sh[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pt = lane & 15, g = lane >> 4;
     const int grp = blockIdx.x / a.bpg, wg_row0 = blockIdx.x * C::ROWS;
     Rk45State *st = a.st + grp;
     if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
-    const size_t n = (size_t)a.nrows * POSE;
+    const size_t n = (size_t)a.nrows * NC;
     const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
     const float *tvec = a.tvec + ((size_t)grp * 8 + slot) * HEADS;
     const double h = st->h;
     const float sigma = st->stage_sigma[slot];
     const double g2 = st->stage_g2[slot];
     const bool commit = STAGE == 1 && st->last_accepted;
-    const int nown = g < 2 ? 4 : (g == 2 ? 1 : 0);  // components 4g .. of a 9-vector this lane owns
+    const int nown = g < 2 ? 4 : (g == 2 ? NC - 8 : 0);  // components 4g .. of the row's NC-vector this lane owns
     // ---- stage input: y (+ h * sum_q a_sq K_q) in f64 (requests first, the ring prologue behind them)
     double yv[PT][4];
     size_t ge0[PT];
     bool live[PT];
+    float pr[PT][POSE];  // MODEL 2: the row's Hutchinson probe (all nine components in every lane of the row)
+    f32x4 prf[PT];       //          and the components 4g .. 4g+3 this lane's gx components meet
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int row = wg_row0 + (wave * PT + p) * 16 + pt;
         live[p] = row < a.nrows;
         const int r = live[p] ? row : a.nrows - 1;  // rows past the end: clamped duplicates (computed, never stored)
-        ge0[p] = (size_t)r * POSE + 4 * g;
+        ge0[p] = (size_t)r * NC + 4 * g;
+        if constexpr (MODEL == 2) {
+#pragma unroll
+            for (int j = 0; j < POSE; ++j) pr[p][j] = a.probe[(size_t)r * POSE + j];
+            prf[p] = gp_chain::pose_fragment(pr[p], g);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             yv[p][c] = 0.0;
@@ -289,19 +299,59 @@ __global__ __launch_bounds__(gp_chain::NT, 1) void rk45_stage_chain_kernel(OdeAr
     gp_chain::begin<PT>(cs, lds, net, a.cvec, tvec, wg_row0, a.nrows, a.kcand);
     f32x4 xf[PT];
 #pragma unroll
-    for (int p = 0; p < PT; ++p) xf[p] = f32x4{(float)yv[p][0], (float)yv[p][1], (float)yv[p][2], (float)yv[p][3]};
+    for (int p = 0; p < PT; ++p) {
+        xf[p] = f32x4{(float)yv[p][0], (float)yv[p][1], (float)yv[p][2], (float)yv[p][3]};
+        if (NC > POSE && g == 2) xf[p].y = 0.f;  // the log-density component is no network input
+    }
     float f[PT][POSE];
-    gp_chain::run<PT>(cs, lds, net, xf, f);
+    f32x4 gx[PT];
+    float extra[PT];  // MODEL 2: the divergence estimate (J_f^T u) . probe of the row, in every lane
+    if constexpr (MODEL == 0) {
+        gp_chain::run<PT>(cs, lds, net, xf, f);
+    } else {
+        float u[PT][POSE];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int j = 0; j < POSE; ++j) {
+                if constexpr (MODEL == 1)
+                    u[p][j] = __shfl(xf[p][j & 3], pt + 16 * (j >> 2), 64) / sigma;  // u = x / sigma, x gathered from the lane group that owns it
+                else
+                    u[p][j] = pr[p][j] / (sigma + 1e-7f);
+            }
+        gp_chain::store_cotangent<PT>(lds, u);
+        gp_chain::run_vjp<PT>(cs, lds, net, xf, f, gx);
+        if constexpr (MODEL == 2) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                float e = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e += gx[p][q] * prf[p][q];  // (components beyond 8: both factors are zero)
+                e += __shfl_xor(e, 16, 64);
+                e += __shfl_xor(e, 32, 64);
+                extra[p] = e;
+            }
+        }
+    }
     double *Kout = a.K + (size_t)(STAGE == 7 ? 1 : (STAGE == 0 ? 0 : (STAGE == 6 ? 6 : STAGE))) * n;
     double acc0 = 0.0, acc1 = 0.0;
+    f32x4 ff[PT];  // f_theta components 4g .. 4g+3 of the lane's rows
+#pragma unroll
+    for (int p = 0; p < PT; ++p) ff[p] = gp_chain::pose_fragment(f[p], g);
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c >= nown || !live[p]) continue;
-            const float fc = g == 0 ? f[p][c] : (g == 1 ? f[p][4 + c] : f[p][8]);
+            const float fc = ff[p][c];
             const size_t ge = ge0[p] + c;
-            const float rhs = fc / (sigma + 1e-7f);
+            float rhs;
+            if constexpr (MODEL == 0)
+                rhs = fc / (sigma + 1e-7f);
+            else if constexpr (MODEL == 1)
+                rhs = fc / sigma + gx[p][c];  // d/dx <x, f(x)/sigma> (energynet.py:200-222)
+            else
+                rhs = (g == 2 && c == 1) ? extra[p] : fc / (sigma + 1e-7f);  // component 9: the divergence estimate (samplers.py:83-86)
             const double kv = 0.0 - (0.5 * g2) * (double)rhs;
             Kout[ge] = kv;
             if (STAGE == 0) {
@@ -673,17 +723,16 @@ int set_lds_attr(K kern, size_t lds) {
 template <int P, int MODEL, bool CHAIN = false>
 static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double *traj, int traj_cap, double t0, double t_bound, double rtol,
                            double atol, double denoise_scale, int do_denoise, int nstates, const float *centre, double *x_out, hipStream_t st) {
-    static_assert(!CHAIN || MODEL == 0, "the chain form serves the score model");
-    using CC = gp_chain::Cfg<2>;
+    const size_t chain_lds = MODEL == 0 ? gp_chain::Cfg<2>::LDS_BYTES : gp_chain::CfgV<2>::LDS_BYTES;
     const double *y = a.y;
     const size_t lds = MODEL == 0 ? trunk_lds_bytes<P>() : gp_bwd::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
         if constexpr (CHAIN) {
-            if (set_lds_attr(rk45_stage_chain_kernel<2, 0>, CC::LDS_BYTES) || set_lds_attr(rk45_stage_chain_kernel<2, 1>, CC::LDS_BYTES) ||
-                set_lds_attr(rk45_stage_chain_kernel<2, 2>, CC::LDS_BYTES) || set_lds_attr(rk45_stage_chain_kernel<2, 3>, CC::LDS_BYTES) ||
-                set_lds_attr(rk45_stage_chain_kernel<2, 4>, CC::LDS_BYTES) || set_lds_attr(rk45_stage_chain_kernel<2, 5>, CC::LDS_BYTES) ||
-                set_lds_attr(rk45_stage_chain_kernel<2, 6>, CC::LDS_BYTES) || set_lds_attr(rk45_stage_chain_kernel<2, 7>, CC::LDS_BYTES))
+            if (set_lds_attr(rk45_stage_chain_kernel<2, 0, MODEL>, chain_lds) || set_lds_attr(rk45_stage_chain_kernel<2, 1, MODEL>, chain_lds) ||
+                set_lds_attr(rk45_stage_chain_kernel<2, 2, MODEL>, chain_lds) || set_lds_attr(rk45_stage_chain_kernel<2, 3, MODEL>, chain_lds) ||
+                set_lds_attr(rk45_stage_chain_kernel<2, 4, MODEL>, chain_lds) || set_lds_attr(rk45_stage_chain_kernel<2, 5, MODEL>, chain_lds) ||
+                set_lds_attr(rk45_stage_chain_kernel<2, 6, MODEL>, chain_lds) || set_lds_attr(rk45_stage_chain_kernel<2, 7, MODEL>, chain_lds))
                 return GP_ELAUNCH;
         }
         if (set_lds_attr(rk45_stage_kernel<P, 0, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 1, MODEL>, lds) ||
@@ -708,7 +757,7 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
     auto stage = [&](auto tag) {
         constexpr int S = decltype(tag)::value;
         if constexpr (CHAIN)
-            hipLaunchKernelGGL((rk45_stage_chain_kernel<2, S>), grid, dim3(gp_chain::NT), CC::LDS_BYTES, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_chain_kernel<2, S, MODEL>), grid, dim3(gp_chain::NT), chain_lds, st, a, *net);
         else
             hipLaunchKernelGGL((rk45_stage_kernel<P, S, MODEL>), grid, blk, lds, st, a, *net);
     };
@@ -835,9 +884,9 @@ static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *pro
     if (model < 0 || model > 2 || (model == 2 && !probe)) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
     // launch plan of the stage kernels (score_trunk.h: score_plan_rows): 16 / 32-row tiles or the 128-row chain form; plan != 0 forces one
-    int P = model == 0 ? (plan ? plan : score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k)) : 16;
+    int P = plan ? plan : (model == 0 ? score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k) : score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k));
     if (P != 16 && P != 32 && P != 128) return GP_EINVAL;
-    if (model != 0 && P != 16) return GP_EINVAL;
+    if (model != 0 && P == 32) return GP_EINVAL;  // forward + backward: 16-row tiles (score_bwd.h) or the 128-row chain form (trunk_chain_vjp.h)
     if (P == 128 && !gp_chain::Cfg<2>::fits(k)) return GP_EINVAL;
     if (ngroups > 1 && rg % P != 0) return GP_EINVAL;  // workgroups must not straddle groups
     a->nrows = ngroups * rg, a->kcand = k;
@@ -878,8 +927,11 @@ int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int 
     if (model != 0 && (!net->w_headx_t || !net->w_pose2_t || !net->w_pose0_t)) return GP_EINVAL;
 #define GP_RK45_CALL(PP, MM) \
     rk45_phase_impl<PP, MM>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out, (hipStream_t)s)
-    if (model == 1) return GP_RK45_CALL(16, 1);
-    if (model == 2) return GP_RK45_CALL(16, 2);
+#define GP_RK45_CHAIN(MM) \
+    rk45_phase_impl<16, MM, true>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out, (hipStream_t)s)
+    if (model == 1) return P == 128 ? GP_RK45_CHAIN(1) : GP_RK45_CALL(16, 1);
+    if (model == 2) return P == 128 ? GP_RK45_CHAIN(2) : GP_RK45_CALL(16, 2);
+#undef GP_RK45_CHAIN
     if (P == 128)
         return rk45_phase_impl<32, 0, true>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
                                             (hipStream_t)s);
@@ -889,8 +941,8 @@ int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int 
 
 int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k) {
     if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || model < 0 || model > 2) return GP_EINVAL;
-    if (model != 0) return 16;
     const int rg = nclouds_per_group * k;
+    if (model != 0) return score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
     return score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
 }
 

@@ -339,6 +339,23 @@ static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
     if (c128 < cb) best = 128, cb = c128;
     return cb < inf ? best : -1;
 }
+// The same choice for the forward + vector-Jacobian right-hand sides (energy model's score, likelihood ODE): 16-row tiles (score_bwd.h)
+// or the 128-row chain form (trunk_chain_vjp.h).  Measured on MI355X, K = 50, us per launch of the energy model's PC step
+// (profiles/r4_vjp_plans.txt):
+//     rows     3200  12800  32000  64000
+//     16       48.1  180.0  372.6  788     (0.45 - 0.58 of the fp32 MFMA peak on 2 x 0.5335 MFLOP per row)
+//     128     285.9  287.9  292.2  601     (0.74 at 32 000 rows)
+// i.e. a round of one workgroup per CU costs ~47 / ~288 us: the chain form from ~24 600 rows.
+constexpr float TILE16_VJP_ROUND_US = 47.0f, CHAIN128_VJP_ROUND_US = 288.0f;
+static inline int score_plan_rows_vjp(int nrows, int rows_per_group, int kcand) {
+    const bool fits128 = (rows_per_group <= 0 || rows_per_group % 128 == 0) && (128 - 2 + kcand) / kcand + 1 <= 4;
+    const bool fits16 = rows_per_group <= 0 || rows_per_group % 16 == 0;
+    const int ncu = gp_num_cus();
+    const float c16 = fits16 ? TILE16_VJP_ROUND_US * (((nrows + 15) / 16 + ncu - 1) / ncu) : 1e30f;
+    const float c128 = fits128 ? CHAIN128_VJP_ROUND_US * (((nrows + 127) / 128 + ncu - 1) / ncu) : 1e30f;
+    if (c16 >= 1e30f && c128 >= 1e30f) return -1;
+    return c128 < c16 ? 128 : 16;
+}
 // tile form only (entry points that have no chain form: ragged RK45 groups, the backward kernels)
 static inline int score_tile_rows(int nrows) {
     const int ncu = gp_num_cus();

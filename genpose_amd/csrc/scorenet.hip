@@ -9,7 +9,7 @@
 // The three heads are stacked into one 768-wide layer; their 256->3 output layers are applied in the
 // accumulator epilogue (no 768-wide activation ever reaches LDS).
 #include "score_bwd.h"
-#include "trunk_chain.h"
+#include "trunk_chain_vjp.h"
 
 namespace {
 
@@ -302,7 +302,10 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
 // of a row's four lane groups carries the row's 9-vector (the update is ~150 VALU instructions per wave, computed redundantly by
 // the four groups - cheaper than any exchange), lane group 0 stores.  One partial sum of |score| per WAVE; the batch-mean
 // gradient norm is reduced from them by every wave in the same fixed order (identical in all waves: deterministic).
-template <int PT>
+// MODEL 1: the ENERGY network - its score, the gradient of the inner-product energy, from the forward + vector-Jacobian chain of
+// trunk_chain_vjp.h (cotangent u = x / sigma; score = f / sigma + J_f^T u, energynet.py:200-222) - what pc_step_kernel<16, 1> computes
+// per 16-row tile through LDS.
+template <int PT, int MODEL>
 __global__ __launch_bounds__(gp_chain::NT, 1) void pc_step_chain_kernel(PcArgs a, gp_scorenet net) {
     using C = gp_chain::Cfg<PT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -397,14 +400,31 @@ __global__ __launch_bounds__(gp_chain::NT, 1) void pc_step_chain_kernel(PcArgs a
 #pragma unroll
     for (int p = 0; p < PT; ++p) xf[p] = gp_chain::pose_fragment(xv[p], g);
     float f[PT][POSE];
-    gp_chain::run<PT>(st, lds, net, xf, f);
+    float gx9[PT][POSE];  // MODEL 1: J_f^T u, every lane of a row holds all nine components
+    if constexpr (MODEL == 0) {
+        gp_chain::run<PT>(st, lds, net, xf, f);
+    } else {
+        float u[PT][POSE];
+        f32x4 gx[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int j = 0; j < POSE; ++j) u[p][j] = xv[p][j] / sigma;
+        gp_chain::store_cotangent<PT>(lds, u);
+        gp_chain::run_vjp<PT>(st, lds, net, xf, f, gx);
+        // lane (row, g) holds components 4g .. 4g+3: hand every lane of the row all nine
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int j = 0; j < POSE; ++j) gx9[p][j] = __shfl(gx[p][j & 3], pt + 16 * (j >> 2), 64);
+    }
     float nsum = 0.f;
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         float q = 0.f, sc9[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            sc9[j] = f[p][j] / (sigma + 1e-7f);
+            sc9[j] = MODEL == 0 ? f[p][j] / (sigma + 1e-7f) : f[p][j] / sigma + gx9[p][j];
             q += sc9[j] * sc9[j];
         }
         if (row[p] < a.nrows && g == 0) {
@@ -438,15 +458,15 @@ static int launch_eval_chain(int R, int k, const gp_scorenet *net, const float *
     return gp_launch_status();
 }
 
-template <int PT>
+template <int PT, int MODEL>
 static int launch_pc_chain(const PcArgs &a, const gp_scorenet *net, int nwg, hipStream_t st) {
-    using C = gp_chain::Cfg<PT>;
+    const size_t lds = MODEL == 0 ? gp_chain::Cfg<PT>::LDS_BYTES : gp_chain::CfgV<PT>::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        if (set_lds(pc_step_chain_kernel<PT>, C::LDS_BYTES)) return GP_ELAUNCH;
+        if (set_lds(pc_step_chain_kernel<PT, MODEL>, lds)) return GP_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((pc_step_chain_kernel<PT>), dim3(nwg), dim3(gp_chain::NT), C::LDS_BYTES, st, a, *net);
+    hipLaunchKernelGGL((pc_step_chain_kernel<PT, MODEL>), dim3(nwg), dim3(gp_chain::NT), lds, st, a, *net);
     return gp_launch_status();
 }
 
@@ -528,9 +548,9 @@ int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k,
     if ((model != 0 && model != 1) || ngroups <= 0 || nclouds_per_group < 0 || k <= 0 || !tile_out || !nparts_out) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
     int P = tile;
-    if (model == 1) {  // the energy model's score needs the backward pass: 16-row tiles
-        if (P != 0 && P != 16) return GP_EINVAL;
-        P = 16;
+    if (model == 1) {  // the energy model's score needs the backward pass: 16-row tiles (score_bwd.h) or the 128-row chain form (trunk_chain_vjp.h)
+        if (P == 0) P = score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
+        if (P != 16 && P != 128) return GP_EINVAL;
     }
     if (P == 0) P = score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
     if (P != 16 && P != 32 && P != 128) return GP_EINVAL;
@@ -563,7 +583,7 @@ int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int
     a.gn_ext = gn_ext, a.ngroups = ngroups, a.gn_rows = (float)gn_rows_total;
     hipStream_t st = (hipStream_t)s;
     const int nwg = a.wgpg * ngroups;
-    if (P == 128) return launch_pc_chain<2>(a, net, nwg, st);
+    if (P == 128) return model == 1 ? launch_pc_chain<2, 1>(a, net, nwg, st) : launch_pc_chain<2, 0>(a, net, nwg, st);
     static bool attr_done = false;
     if (!attr_done) {
         if (set_lds(pc_step_kernel<16, 0>, trunk_lds_bytes<16>()) || set_lds(pc_step_kernel<32, 0>, trunk_lds_bytes<32>()) ||

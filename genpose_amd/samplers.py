@@ -55,7 +55,7 @@ class PCSampler:
                              "run the batches separately")
         self.tile, self.nparts = t_out.value, n_out.value
         self.kernel_name = (f"pc_step_kernel<{self.tile}>" if self.model == 0 else f"pc_step_kernel<{self.tile},energy>") if self.tile in (16, 32) else \
-            "pc_step_chain_kernel<2>"
+            ("pc_step_chain_kernel<2>" if self.model == 0 else "pc_step_chain_kernel<2,energy>")
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)
         self.tvec_all = net.time_embed(ts.to(self.dev))
@@ -190,9 +190,9 @@ class ODESampler:
         self.net, self.B, self.K, self.groups = net, B, K, groups
         R = self.R = B * K
         if not self.ragged:
-            # the backward pass (energy model, likelihood) runs on 16-row tiles
+            # forward + backward right-hand sides (energy model, likelihood): 16-row tiles or, for large launches, the 128-row chain form
             self.tile = int(tile) if tile else _lib.lib().gp_rk45_plan_rows(self.model, groups, B // groups, K)
-            if self.tile not in (16, 32, 128) or (self.model != 0 and self.tile != 16) or (groups > 1 and (R // groups) % self.tile):
+            if self.tile not in (16, 32, 128) or (self.model != 0 and self.tile == 32) or (groups > 1 and (R // groups) % self.tile):
                 raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                                  "run the batches separately")
             self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)

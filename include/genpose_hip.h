@@ -242,7 +242,8 @@ int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k,
  * plan) and the MODEL whose score drives the sampler: 0 = the score network (f / (sigma + 1e-7), scorenet.py:217); 1 = the ENERGY
  * network (`net` = its parameter block): the reference samples from it with the autograd gradient of its inner-product energy
  * (posenet.py:94-130 with PoseEnergyNet.forward(return_item='score'), energynet.py:200-222) - here the forward pass and the
- * vector-Jacobian product run inside the step kernel (16-row tiles), so the energy model gets the same one-graph launch chain.
+ * vector-Jacobian product run inside the step kernel (tile = 16: through LDS, csrc/score_bwd.h; tile = 128: the register-resident chain
+ * form, csrc/trunk_chain_vjp.h, which large launches take), so the energy model gets the same one-graph launch chain.
  * gn_ext / gn_rows_total: as gp_pc_step_coupled when gn_rows_total = 0 (gn_ext = the mean); with gn_rows_total > 0, gn_ext [nsteps][ngroups]
  * holds the SUM of |score| over all rows of the batch (this rank's per-group sum of `partials`, all-reduced in place) and
  * gn_rows_total that row count: one device-side sum and one all-reduce per step, both capturable in the sampler's hipGraph. */
@@ -309,8 +310,9 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
  * squares to ext_sums; the caller all-reduces ext_sums (RCCL: capturable with the launches) and runs phase 11, 12 or 13 = the step
  * controller on the reduced sums (+ trajectory record).  Every shard then takes the accept / reject sequence of the unsharded batch.
  * ext_sums = NULL: the controller reduces the local partials itself (phases 11-13 are GP_EINVAL).
- * plan: rows per workgroup of the stage kernels - 16 / 32 = tile form, 128 = the chain form of the trunk (score model only; k >= 43,
- * rows_per_group % 128 == 0 when ngroups > 1); 0 = gp_rk45_plan_rows() picks.  partials [3][ngroups * ceil(rows_per_group / plan)]. */
+ * plan: rows per workgroup of the stage kernels - 16 / 32 = tile form (models 1 and 2, which need the backward pass: 16 only), 128 = the
+ * chain form of the trunk (every model; k >= 43, rows_per_group % 128 == 0 when ngroups > 1); 0 = gp_rk45_plan_rows() picks.
+ * partials [3][ngroups * ceil(rows_per_group / plan)]. */
 int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k);
 int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,

@@ -145,7 +145,12 @@ def test_launch_plans_are_consistent():
     from genpose_amd import _lib
     L = _lib.lib()
     assert L.gp_rk45_plan_rows(0, 1, 64, 50) == 16 and L.gp_rk45_plan_rows(0, 10, 64, 50) == 128
-    assert L.gp_rk45_plan_rows(1, 10, 64, 50) == 16 and L.gp_rk45_plan_rows(2, 10, 64, 50) == 16
+    # forward + backward right-hand sides (energy model's score, likelihood): 16-row tiles, or the 128-row chain form for large launches
+    assert L.gp_rk45_plan_rows(1, 1, 64, 50) == 16 and L.gp_rk45_plan_rows(2, 1, 64, 50) == 16
+    assert L.gp_rk45_plan_rows(1, 10, 64, 50) == 128 and L.gp_rk45_plan_rows(2, 10, 64, 50) == 128
+    assert L.gp_rk45_plan_rows(1, 10, 64, 10) == 16  # k < 43: no chain form
+    assert L.gp_pc_layout(1, 0, 10, 64, 50, ctypes.byref(ctypes.c_int(0)), ctypes.byref(ctypes.c_int(0))) == 0
+    assert L.gp_pc_layout(1, 32, 1, 64, 50, ctypes.byref(ctypes.c_int(0)), ctypes.byref(ctypes.c_int(0))) != 0  # no 32-row form of the backward pass
     assert L.gp_rk45_plan_rows(0, 10, 64, 10) in (16, 32)  # k < 43: a 128-row workgroup would span more clouds than it stages
     assert L.gp_rk45_plan_rows(0, 0, 64, 50) < 0 and L.gp_rk45_plan_rows(3, 1, 64, 50) < 0
     t, n = ctypes.c_int(0), ctypes.c_int(0)

@@ -154,7 +154,7 @@ def test_energy_model_samplers_are_device_resident_and_grouped():
         np.testing.assert_allclose(got[:, :6], want[:, :6], rtol=0, atol=2e-3, err_msg=f"batch {g}")
         np.testing.assert_allclose(got[:, 6:], want[:, 6:], rtol=0, atol=1e-3 * max(1.0, float(np.abs(want[:, 6:]).max())), err_msg=f"batch {g}")
     with pytest.raises(ValueError):
-        PCSampler(net, 640, 50, n, "cuda", groups=10, model="energy", tile=128)  # the backward pass runs on 16-row tiles
+        PCSampler(net, 640, 50, n, "cuda", groups=10, model="energy", tile=32)  # the backward pass has no 32-row tile form (16, or the chain form)
     # ODE: two batches, each with its own step controller == the oracle's solve of that batch alone (attempt for attempt)
     T0 = 0.3
     y0 = torch.randn(G * R1, 9, generator=gen) * float(go.ve_sigma(torch.tensor(T0)))
