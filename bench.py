@@ -289,6 +289,7 @@ def main():
             side["full_pipeline_256"] = full_pipeline_leg(torch, K, n, str(dev))
             side["drop_in_eval_single"] = drop_in_leg(torch, str(dev), K)
             side["config0_single_object"] = config0_leg(torch, str(dev))
+            side["energy_model_pc_step"] = energy_model_leg(torch, str(dev), B, K, G)
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
@@ -417,7 +418,7 @@ def tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend):
             "whole_path_tflops": round(value * flop_per_pose / 1e12, 2), "roofline": None, "cpu_baseline": None}), flush=True)
 
 
-def pc_roofline(torch, smp, rows, n):
+def pc_roofline(torch, smp, rows, n, flop_row=FLOP_SCORE_ROW):
     """`achieved` = algorithmic FLOPs of one FULL pc_step launch / its average duration.  The sampler graph is exactly n full
     launches + the short finish-only launch; both are timed with HIP events on the launch stream with nothing else in flight and
     the finish-only launch is subtracted, so the average is over full launches only."""
@@ -445,7 +446,7 @@ def pc_roofline(torch, smp, rows, n):
     torch.cuda.synchronize()
     fin_s = min(f0.elapsed_time(f1) * 1e-3 / nfin, chain_s / (n + 1))
     per_launch_s = (chain_s - fin_s) / n
-    flops_per_launch = rows * FLOP_SCORE_ROW
+    flops_per_launch = rows * flop_row
     ach = flops_per_launch / per_launch_s / 1e12
     roofline = {"bound": "mfma", "kernel": smp.kernel_name, "rows_per_launch": rows, "achieved": round(ach, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
@@ -676,6 +677,27 @@ def config0_leg(torch, dev):
         out[name] = {"ms_per_call": round(dt * 1e3, 3), "poses_per_s": round(B / dt, 1)}
         if sampler == "ode":
             out[name]["nfev"] = int(sa.net.last_sampler.last_stats["nfev"])
+    return out
+
+
+def energy_model_leg(torch, dev, B, K, G, n=20):
+    """Roofline of the forward + vector-Jacobian right-hand side: the PC step of a sampler that draws FROM the energy model (its score is
+    the gradient of the inner-product energy, energynet.py:200-222: forward pass + backward pass per evaluation, 2 x 0.5335 MFLOP per row
+    on the minimal count) at the benched launch size (G x B clouds x K candidates), chain form (csrc/trunk_chain_vjp.h), and the 16-row
+    tile form (csrc/score_bwd.h) beside it."""
+    from genpose_amd.samplers import PCSampler
+    from genpose_amd.scorenet import ScoreNetHIP
+    from genpose_amd.weights_synth import make_state_dict
+    net = ScoreNetHIP(make_state_dict(0, "energy"), dev)
+    out = {}
+    for tile in (0, 16):
+        smp = PCSampler(net, G * B, K, n, dev, groups=G, model="energy", tile=tile)
+        cvec, centre = torch.randn(G * B, 768, device=dev), torch.randn(G * B, 3, device=dev)
+        x0 = torch.randn(G * B * K, 9, device=dev) * 50.0
+        for _ in range(2):
+            smp.run(cvec, centre, x0)
+        r = pc_roofline(torch, smp, G * B * K, n, flop_row=2 * FLOP_SCORE_ROW)
+        out["plan" if tile == 0 else "tile16"] = {k: r[k] for k in ("kernel", "rows_per_launch", "avg_launch_us", "achieved", "frac", "flops_per_launch")}
     return out
 
 

@@ -87,29 +87,49 @@ def test_ode_energy_model_chain_vs_tile_and_oracle():
 
 
 def test_likelihood_chain_vs_tile():
-    """The ten-component likelihood ODE (pose + log-density, samplers.py:22-99) with the chain-form stages: the tile form's solve,
-    attempt for attempt, and its log-likelihoods."""
+    """The ten-component likelihood ODE (pose + log-density, samplers.py:22-99) with the chain-form stages.  (1) The right-hand side itself
+    - score and Hutchinson divergence estimate of every row, as the first two evaluations of the solve write them (f0 at t = eps, f1 after
+    the trial Euler step) - against the tile form's: 1e-5 of the largest component.  (2) The whole solve (~900 attempts at rtol 1e-4 on
+    a random-weight network with a probe of scale 50 - a chaotic problem: the two forms' right-hand sides differ at the 1e-7 level and the
+    step-size feedback carries that into the schedule): attempt counts within 10 %, log-likelihoods within 1 % for all but a few rows."""
     from genpose_amd.likelihood import cond_ode_likelihood
     from genpose_amd.samplers import ODESampler
     net = _net("score")
     B, K = 3, 50
+    R = B * K
     gen = torch.Generator().manual_seed(5)
     pf = torch.randn(B, 1024, generator=gen).abs().cuda()
-    x = torch.randn(B * K, 9, generator=gen).cuda()
-    probe = (torch.randn(B * K, 9, generator=gen) * 50.0).cuda()
+    x = torch.randn(R, 9, generator=gen).cuda()
+    probe = (torch.randn(R, 9, generator=gen) * 50.0).cuda()
     cvec = net.cloud_embed(pf)
-    res = {}
+    res, rhs = {}, {}
     for tile in (16, 128):
         solver = ODESampler(net, B, K, "cuda", model="likelihood", tile=tile)
         assert solver.tile == tile
+        # (1) the first two right-hand-side evaluations of the solve (phases 0-2 of run_likelihood)
+        solver.cvec.copy_(cvec)
+        solver.centre.zero_()
+        solver.probe.copy_(probe)
+        y0 = solver.y.view(R, 10)
+        y0[:, :9].copy_(x.double())
+        y0[:, 9].zero_()
+        solver._phase(0, None, t0=1e-5, t_bound=1.0, rtol=1e-4, atol=1e-4)
+        solver._phase(1, None)
+        solver._phase(2, None)
+        torch.cuda.synchronize()
+        rhs[tile] = solver.Kbuf[:2].view(2, R, 10).cpu().numpy().copy()
         st = {}
         z, ll = cond_ode_likelihood(net, cvec, K, x, probe, rtol=1e-4, atol=1e-4, stats=st, solver=solver)
         res[tile] = (z.cpu().numpy(), ll.cpu().numpy(), st)
-    # ~900 attempts at rtol 1e-4 on a random-weight network: the two forms' right-hand sides differ at the 1e-7 level and the step-size
-    # feedback (err^-1/5) carries that into the schedule - the attempt counts agree to a few per cent (measured 5 %), the results below to 2e-3
+    for q in range(2):
+        for comps, what in ((slice(0, 9), "score"), (slice(9, 10), "divergence estimate")):
+            a, b = rhs[128][q][:, comps], rhs[16][q][:, comps]
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-5 * np.abs(b).max(), err_msg=f"evaluation {q}, {what}")
+    assert np.abs(rhs[16][0][:, 9]).max() > 0  # the divergence component is live
     assert abs(res[128][2]["nfev"] - res[16][2]["nfev"]) <= 0.1 * res[16][2]["nfev"], (res[128][2], res[16][2])
-    np.testing.assert_allclose(res[128][1], res[16][1], rtol=2e-3, atol=2e-3 * np.abs(res[16][1]).max())
-    np.testing.assert_allclose(res[128][0], res[16][0], rtol=0, atol=2e-3 * max(1.0, np.abs(res[16][0]).max()))
+    rel = np.abs(res[128][1] - res[16][1]) / np.abs(res[16][1]).max()
+    assert np.quantile(rel, 0.95) < 1e-2 and rel.max() < 1e-1, (np.quantile(rel, 0.95), rel.max())
+    np.testing.assert_allclose(res[128][0], res[16][0], rtol=0, atol=2e-2 * max(1.0, np.abs(res[16][0]).max()))
 
 
 def test_large_launches_take_the_chain_form():
