@@ -399,6 +399,24 @@ def tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend):
     times = sorted(b[0] for b in blocks)
     elapsed = statistics.median(times)
     nfev = statistics.median(blocks[-1][1])
+    single = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # latency of ONE sequence processed frame by frame (runner.TrackingRunner: a frame = two hipGraphs around the adaptive solve, the
+        # energy model's encoder underneath the solve) - what evaluation_tracking.py's loop does, one call per frame
+        from genpose_amd.runner import TrackingRunner
+        tr = TrackingRunner(sa, ea, repeat_num=K, T0=T0)
+        frames_1, names_1, gt_1 = seqs[0]
+        for f in range(8):
+            tr.step(frames_1[f % nfr], names_1, gt_1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nf = 60
+        for f in range(nf):
+            tr.step(frames_1[(8 + f) % nfr], names_1, gt_1)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / nf
+        single = {"ms_per_frame": round(dt1 * 1e3, 3), "frames_per_s": round(1.0 / dt1, 1), "objects_per_frame": n_obj, "nfev": int(sa.net.last_sampler.last_stats["nfev"]) ,
+                  "workload": "one sequence, one TrackingRunner.step per frame"}
     if rank == 0:
         value = world * S * n_obj * args.steps / elapsed
         flop_per_pose = 2 * (FLOP_ENCODER + FLOP_CLOUD_EMBED) + K * (nfev + 1) * FLOP_SCORE_ROW
@@ -415,7 +433,7 @@ def tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend):
                        "block_ms_min": round(times[0] * 1e3, 3), "block_ms_max": round(times[-1] * 1e3, 3), "statistic": "median block"},
             "launch": {"mode": os.environ.get("GP_BENCH_LAUNCH", "direct" if world == 1 else "torch.distributed.run"),
                        "world_size_observed": (dist.get_world_size() if dist is not None else 1), "backend": backend},
-            "whole_path_tflops": round(value * flop_per_pose / 1e12, 2), "roofline": None, "cpu_baseline": None}), flush=True)
+            "whole_path_tflops": round(value * flop_per_pose / 1e12, 2), "roofline": None, "cpu_baseline": None, "single_sequence": single}), flush=True)
 
 
 def pc_roofline(torch, smp, rows, n, flop_row=FLOP_SCORE_ROW):

@@ -241,13 +241,6 @@ __device__ __forceinline__ void dense_to_lds(const float *Xs, int ld, const floa
     return dense_to_lds_w<P / 16, 4, RELU>(Xs, ld, Wp, bias, K, N, Ys, ldo);
 }
 
-// Hoisted first layer of a set-abstraction scale, one channel: base + wx dx + wy dy + wz dz as ONE fmaf chain (3 VALU instructions; the
-// library is built with -ffp-contract=off, so the plain expression is three multiplications and three additions).  Every SA kernel uses
-// this form, so the implementations of a scale agree to the last bit in layer 1.
-__device__ __forceinline__ float sa_l1(float base, float wx, float wy, float wz, float dx, float dy, float dz) {
-    return fmaf(wz, dz, fmaf(wy, dy, fmaf(wx, dx, base)));
-}
-
 // Wave-wide float sum on DPP row operations (VALU speed, fixed order -> deterministic); result valid in EVERY lane
 // (read back from lane 63 as a wave-uniform scalar).
 template <int CTRL, int ROW_MASK>

@@ -367,10 +367,10 @@ __global__ __launch_bounds__(256) void sa_pre_mlp_kernel(SAPreArgs a) {
             const f32x4 w1 = *reinterpret_cast<const f32x4 *>(a.wxyz + (4 * q + 1) * 4);
             const f32x4 w2 = *reinterpret_cast<const f32x4 *>(a.wxyz + (4 * q + 2) * 4);
             const f32x4 w3 = *reinterpret_cast<const f32x4 *>(a.wxyz + (4 * q + 3) * 4);
-            v.x = sa_l1(v.x, w0.x, w0.y, w0.z, d.x, d.y, d.z);
-            v.y = sa_l1(v.y, w1.x, w1.y, w1.z, d.x, d.y, d.z);
-            v.z = sa_l1(v.z, w2.x, w2.y, w2.z, d.x, d.y, d.z);
-            v.w = sa_l1(v.w, w3.x, w3.y, w3.z, d.x, d.y, d.z);
+            v.x += w0.x * d.x + w0.y * d.y + w0.z * d.z;
+            v.y += w1.x * d.x + w1.y * d.y + w1.z * d.z;
+            v.z += w2.x * d.x + w2.y * d.y + w2.z * d.z;
+            v.w += w3.x * d.x + w3.y * d.y + w3.z * d.z;
             v.x = fmaxf(v.x, 0.f);
             v.y = fmaxf(v.y, 0.f);
             v.z = fmaxf(v.z, 0.f);
@@ -482,11 +482,11 @@ __global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentre
             f32x4 h1[Q1], h2[Q2];
 #pragma unroll
             for (int q = 0; q < Q1; ++q) {
-                f32x4 v;
-                v.x = sa_l1(bb1[q].x, w1[q][0].x, w1[q][0].y, w1[q][0].z, dx, dy, dz);
-                v.y = sa_l1(bb1[q].y, w1[q][1].x, w1[q][1].y, w1[q][1].z, dx, dy, dz);
-                v.z = sa_l1(bb1[q].z, w1[q][2].x, w1[q][2].y, w1[q][2].z, dx, dy, dz);
-                v.w = sa_l1(bb1[q].w, w1[q][3].x, w1[q][3].y, w1[q][3].z, dx, dy, dz);
+                f32x4 v = bb1[q];
+                v.x += w1[q][0].x * dx + w1[q][0].y * dy + w1[q][0].z * dz;
+                v.y += w1[q][1].x * dx + w1[q][1].y * dy + w1[q][1].z * dz;
+                v.z += w1[q][2].x * dx + w1[q][2].y * dy + w1[q][2].z * dz;
+                v.w += w1[q][3].x * dx + w1[q][3].y * dy + w1[q][3].z * dz;
                 h1[q] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
             }
             // every output chunk of a layer has its own accumulator and the chunks are interleaved k-step by k-step: consecutive
@@ -636,10 +636,10 @@ __global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncen
                 const int g4 = (lo >> 4) * 4;
                 const f32x4 r0 = w1l[16 * q + g4 + 0], r1 = w1l[16 * q + g4 + 1], r2 = w1l[16 * q + g4 + 2], r3 = w1l[16 * q + g4 + 3];
                 f32x4 v = zcur[q];
-                v.x = sa_l1(v.x + r0.w, r0.x, r0.y, r0.z, dx, dy, dz);
-                v.y = sa_l1(v.y + r1.w, r1.x, r1.y, r1.z, dx, dy, dz);
-                v.z = sa_l1(v.z + r2.w, r2.x, r2.y, r2.z, dx, dy, dz);
-                v.w = sa_l1(v.w + r3.w, r3.x, r3.y, r3.z, dx, dy, dz);
+                v.x += (r0.x * dx + r0.y * dy + r0.z * dz) + r0.w;
+                v.y += (r1.x * dx + r1.y * dy + r1.z * dz) + r1.w;
+                v.z += (r2.x * dx + r2.y * dy + r2.z * dz) + r2.w;
+                v.w += (r3.x * dx + r3.y * dy + r3.z * dz) + r3.w;
                 h1[q] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
             }
             // layer 2: two output chunks in flight (independent accumulators hide the 40-cycle dependent MFMA latency)
@@ -825,10 +825,10 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
             const int g4 = (lo >> 4) * 4;
             const f32x4 r0 = w1l[16 * q + g4 + 0], r1 = w1l[16 * q + g4 + 1], r2 = w1l[16 * q + g4 + 2], r3 = w1l[16 * q + g4 + 3];
             f32x4 v = zcur[q];
-            v.x = sa_l1(v.x + r0.w, r0.x, r0.y, r0.z, dx, dy, dz);
-            v.y = sa_l1(v.y + r1.w, r1.x, r1.y, r1.z, dx, dy, dz);
-            v.z = sa_l1(v.z + r2.w, r2.x, r2.y, r2.z, dx, dy, dz);
-            v.w = sa_l1(v.w + r3.w, r3.x, r3.y, r3.z, dx, dy, dz);
+            v.x += (r0.x * dx + r0.y * dy + r0.z * dz) + r0.w;
+            v.y += (r1.x * dx + r1.y * dy + r1.z * dz) + r1.w;
+            v.z += (r2.x * dx + r2.y * dy + r2.z * dz) + r2.w;
+            v.w += (r3.x * dx + r3.y * dy + r3.z * dz) + r3.w;
             h1[q] = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
         }
         load_ops(it + 1, jn, dcur, zcur);
@@ -1008,10 +1008,10 @@ __global__ __launch_bounds__(512) void sa_groupall_ring_kernel(SAPreArgs a, int 
         auto layer1 = [&](int q) {
             const f32x4 r0 = w1l[16 * q + 4 * g + 0], r1 = w1l[16 * q + 4 * g + 1], r2 = w1l[16 * q + 4 * g + 2], r3 = w1l[16 * q + 4 * g + 3];
             f32x4 v = zq[q % 4];
-            v.x = sa_l1(v.x + r0.w, r0.x, r0.y, r0.z, dx, dy, dz);
-            v.y = sa_l1(v.y + r1.w, r1.x, r1.y, r1.z, dx, dy, dz);
-            v.z = sa_l1(v.z + r2.w, r2.x, r2.y, r2.z, dx, dy, dz);
-            v.w = sa_l1(v.w + r3.w, r3.x, r3.y, r3.z, dx, dy, dz);
+            v.x += (r0.x * dx + r0.y * dy + r0.z * dz) + r0.w;
+            v.y += (r1.x * dx + r1.y * dy + r1.z * dz) + r1.w;
+            v.z += (r2.x * dx + r2.y * dy + r2.z * dz) + r2.w;
+            v.w += (r3.x * dx + r3.y * dy + r3.z * dz) + r3.w;
             return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
         };
         f32x4 h1q = layer1(0);  // k-block q + 1 is prepared while k-block q is multiplied

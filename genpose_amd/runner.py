@@ -234,28 +234,39 @@ class TrackingRunner:
 
     def step(self, pts, model_names, gt_RT, noise_draws=None):
         """pts [n,1024,3] device tensor; gt_RT [n,4,4] (used only for objects not seen in the previous frame)."""
-        sample = make_batch_sample(pts)
-        dev = sample["pts"].device
-        with _one_cpu_thread():
-            init_sRT = add_noise_to_RT(gt_RT.float().cpu(), draws=noise_draws).to(dev)  # drawn every frame (:302)
-        for i, name in enumerate(model_names):
-            if name in self.buffer["model_name"]:
-                init_sRT[i] = self.buffer["pred_sRT"][self.buffer["model_name"].index(name)]
-        init_x = init_sRT[:, :3, [0, 1, 3]].permute(0, 2, 1).reshape(init_sRT.shape[0], -1)  # [R[:,0], R[:,1], t]
-        init_x[:, -3:] -= sample["pts_center"]
+        pts = pts.float()
+        dev = pts.device
         K = self.repeat_num
         sel = max(1, int(self.ratio * K))
         # (a coupled agent - its batch sharded over a process group - keeps the agent path: the frame graphs build an uncoupled solver)
-        if self.use_graphs and self.score_agent.cfg.sampler_mode[0] == "ode" and getattr(self.score_agent.net, "coupling_group", None) is None:
-            from .samplers import ODESampler
+        graphs = self.use_graphs and self.score_agent.cfg.sampler_mode[0] == "ode" and getattr(self.score_agent.net, "coupling_group", None) is None
+        if graphs:
             net = self.score_agent.net
             net._need_weights()
             self.energy_agent.net._need_weights()
             if self._graphs is None:
                 self._graphs = _FrameGraphs(net, self.energy_agent.net, K, sel)
-            n = sample["pts"].shape[0]
-            centre, cvec_s, cvec_e = self._graphs.embed(sample["pts"])
-            x0 = init_x.unsqueeze(1).repeat(1, K, 1).view(n * K, -1).float() + net._prior_to_device((n * K, 9), T=self.T0)  # samplers.py:180
+            # graph A first: the clouds' centres come out of it (the mean the sample dict would hold, evaluation_tracking.py:306-311)
+            centre, cvec_s, cvec_e = self._graphs.embed(pts)
+            sample = None
+        else:
+            sample = make_batch_sample(pts)
+            centre = sample["pts_center"]
+        with _one_cpu_thread():
+            noised = add_noise_to_RT(gt_RT.float().cpu(), draws=noise_draws)  # drawn every frame (:302), whether or not it is used
+        if self.buffer["pred_sRT"] is not None and list(model_names) == self.buffer["model_name"]:
+            init_sRT = self.buffer["pred_sRT"].float()  # every object continues from the previous frame: nothing to upload, one tensor
+        else:
+            init_sRT = noised.to(dev)
+            for i, name in enumerate(model_names):
+                if name in self.buffer["model_name"]:
+                    init_sRT[i] = self.buffer["pred_sRT"][self.buffer["model_name"].index(name)]
+        init_x = torch.cat([init_sRT[:, :3, 0], init_sRT[:, :3, 1], init_sRT[:, :3, 3] - centre], dim=1)  # [R[:,0], R[:,1], t - centre]
+        if graphs:
+            from .samplers import ODESampler
+            n = pts.shape[0]
+            prior = net._prior_to_device((n * K, 9), T=self.T0)
+            x0 = (prior.view(n, K, 9) + init_x.float().unsqueeze(1)).view(n * K, 9)  # samplers.py:180: init_x repeated K times + prior
             key = ("ode", n, K, None)
             smp = net._samplers.get(key)
             if smp is None:
@@ -266,7 +277,7 @@ class TrackingRunner:
             energy, sorted_RTs, average_sRT = self._graphs.rank(pred, centre, cvec_e)
             energy, sorted_RTs, average_sRT = energy.clone(), sorted_RTs.clone(), average_sRT.clone()
         else:
-            pred = self.score_agent.pred_func(data=sample, repeat_num=K, save_path=None, init_x=init_x, T0=self.T0)
+            pred = self.score_agent.pred_func(data=sample, repeat_num=K, save_path=None, init_x=init_x.float(), T0=self.T0)
             energy = self.energy_agent.get_energy(data=sample, pose_samples=pred, T=1e-5)
             r = reward.rank_aggregate(pred, energy, selected_num=sel)
             average_sRT = rotation.quat_trans_to_RT(r["avg_pose"])

@@ -400,7 +400,7 @@ class ODESampler:
                              + (" (call set_groups() with this step's grouping first)" if self.ragged else ""))
         self.cvec[:nb_in].copy_(cvec)
         self.centre[:nb_in].copy_(centre)
-        self.y[: nb_in * self.K * 9].copy_(init_x.reshape(-1).double())  # init_x f32 -> f64 state (solve_ivp casts y0 to float64)
+        self.y[: nb_in * self.K * 9].copy_(init_x.reshape(-1))  # init_x f32 -> f64 state in the copy (solve_ivp casts y0 to float64)
         traj = None
         if dense:
             # solve_ivp(t_eval=np.linspace(T0, eps, num_steps)): 4th-order dense output at every t_eval point
