@@ -885,8 +885,8 @@ static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *pro
     const int rg = nclouds_per_group * k;
     // launch plan of the stage kernels (score_trunk.h: score_plan_rows): 16 / 32-row tiles or the 128-row chain form; plan != 0 forces one
     int P = plan ? plan : (model == 0 ? score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k) : score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k));
-    if (P != 16 && P != 32 && P != 128) return GP_EINVAL;
-    if (model != 0 && P == 32) return GP_EINVAL;  // forward + backward: 16-row tiles (score_bwd.h) or the 128-row chain form (trunk_chain_vjp.h)
+    if (P != 16 && P != 32 && P != 64 && P != 128) return GP_EINVAL;
+    if (model != 0 && (P == 32 || P == 64)) return GP_EINVAL;  // forward + backward: 16-row tiles (score_bwd.h) or the 128-row chain form (trunk_chain_vjp.h)
     if (P == 128 && !gp_chain::Cfg<2>::fits(k)) return GP_EINVAL;
     if (ngroups > 1 && rg % P != 0) return GP_EINVAL;  // workgroups must not straddle groups
     a->nrows = ngroups * rg, a->kcand = k;
@@ -935,7 +935,7 @@ int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int 
     if (P == 128)
         return rk45_phase_impl<32, 0, true>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
                                             (hipStream_t)s);
-    return P == 16 ? GP_RK45_CALL(16, 0) : GP_RK45_CALL(32, 0);
+    return P == 16 ? GP_RK45_CALL(16, 0) : (P == 64 ? GP_RK45_CALL(64, 0) : GP_RK45_CALL(32, 0));
 #undef GP_RK45_CALL
 }
 

@@ -31,30 +31,35 @@ struct TrunkCfg {
 // kernel (furthest point sampling, an SA chain kernel of the next batch's encoder) can share the CU with it - and the launch got
 // 3 % FASTER on its own (77.3 -> 75.0 us at 16 000 rows: 37 KB less LDS traffic per head epilogue).  KEEP (the backward pass of
 // gp_score_div reads both hidden activations) keeps H1 and H2 apart.
+// clouds whose (cvec + tvec) rows a tile stages in LDS: a tile whose rows span more reads them from global memory in the head epilogue
+// (the slow path).  16 / 32 rows: two (k >= 31 candidates per cloud guarantees it for 32 rows); 64 rows: three (k >= 32).
+template <int P>
+constexpr int trunk_staged_clouds() { return P >= 64 ? 3 : 2; }
+
 template <int P, bool KEEP = false>
 struct TrunkLds {
     static constexpr bool COMPACT = P >= 32, INPLACE = COMPACT && !KEEP;
-    static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD, LDC = HEADS + 16;
+    static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD, LDC = HEADS + 16, NCLD = trunk_staged_clouds<P>();
     static constexpr int OFF_H1 = P * LD0, OFF_H2 = INPLACE ? OFF_H1 : OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH,
                          NRED = (COMPACT ? 1 : 4) * TrunkCfg<P>::NW,
                          OFF_WOUT = OFF_RED + NRED * P * 12, OFF_CVT = OFF_WOUT + POSE * HID,
-                         TOTAL = OFF_CVT + 2 * LDC;
+                         TOTAL = OFF_CVT + NCLD * LDC;
 };
 
-template <int NV, int NI>
+template <int NV, int NI, int NCLD>
 struct TrunkPreT {
     WStages<NV> stA;  // first-layer weights (stages 0,1)
     f32x4 b0[NV];     // first-layer bias fragments
     float bout[NI];   // output bias of the (row, component) entries this thread combines at the end
     // epilogue operands in flight to LDS (trunk_begin requests, trunk_ftheta parks them)
     static constexpr int NWO = (POSE * HID / 4 + 64 * (16 / NV) - 1) / (64 * (16 / NV));   // float4 per thread: w_out
-    static constexpr int NCV = (2 * HEADS / 4 + 64 * (16 / NV) - 1) / (64 * (16 / NV));    // float4 per thread: cvt
+    static constexpr int NCV = (NCLD * HEADS / 4 + 64 * (16 / NV) - 1) / (64 * (16 / NV));  // float4 per thread: cvt
     f32x4 swo[NWO], scv[NCV], stv[NCV];
     int cloud0;      // first cloud of the tile
-    bool staged;     // tile spans <= 2 clouds (else the epilogue reads cvec/tvec from global memory)
+    bool staged;     // tile spans <= NCLD clouds (else the epilogue reads cvec/tvec from global memory)
 };
 template <int P>
-using TrunkPre = TrunkPreT<TrunkCfg<P>::NV, (P * 9 + TrunkCfg<P>::NT - 1) / TrunkCfg<P>::NT>;
+using TrunkPre = TrunkPreT<TrunkCfg<P>::NV, (P * 9 + TrunkCfg<P>::NT - 1) / TrunkCfg<P>::NT, trunk_staged_clouds<P>()>;
 
 // Entry sequence shared by every kernel that evaluates the trunk: request the first layer's weights and bias
 // (call BEFORE any prologue work so the latency overlaps it).
@@ -76,7 +81,8 @@ __device__ __forceinline__ void trunk_begin(const gp_scorenet &net, TrunkPre<P> 
     // epilogue operands -> registers now, LDS later (trunk_ftheta)
     const int rlast = (row0 + P - 1 < nrows ? row0 + P - 1 : nrows - 1);
     pre.cloud0 = row0 / kcand;
-    pre.staged = rlast / kcand - pre.cloud0 <= 1;
+    constexpr int NCLD = trunk_staged_clouds<P>();
+    pre.staged = rlast / kcand - pre.cloud0 <= NCLD - 1;
 #pragma unroll
     for (int q = 0; q < TrunkPre<P>::NWO; ++q) {
         int f = threadIdx.x + q * NT;
@@ -88,7 +94,7 @@ __device__ __forceinline__ void trunk_begin(const gp_scorenet &net, TrunkPre<P> 
 #pragma unroll
         for (int q = 0; q < TrunkPre<P>::NCV; ++q) {
             int f = threadIdx.x + q * NT;
-            f = f < 2 * HEADS / 4 ? f : 2 * HEADS / 4 - 1;
+            f = f < NCLD * HEADS / 4 ? f : NCLD * HEADS / 4 - 1;
             const int c = f / (HEADS / 4), o = f - c * (HEADS / 4);
             int cl = pre.cloud0 + c;
             cl = cl < nclouds ? cl : nclouds - 1;
@@ -112,7 +118,7 @@ __device__ __forceinline__ void trunk_park_epi(float *lds, TrunkPre<P> &pre) {
 #pragma unroll
         for (int q = 0; q < TrunkPre<P>::NCV; ++q) {
             const int f = threadIdx.x + q * NT;
-            if (f < 2 * HEADS / 4) {
+            if (f < L::NCLD * HEADS / 4) {
                 const int c = f / (HEADS / 4), o = f - c * (HEADS / 4);
                 *reinterpret_cast<f32x4 *>(lds + L::OFF_CVT + c * L::LDC + 4 * o) = pre.scv[q] + pre.stv[q];
             }
@@ -311,17 +317,19 @@ constexpr size_t trunk_lds_bytes() {
 }
 
 // Rows per workgroup of a score launch: which form of the trunk serves `nrows` rows best.
-//   16 / 32   tile form (this file): one 16- or 32-row tile per workgroup.  With 16 rows every weight fragment feeds one MFMA and the
-//             kernel is bound by the CU's L2 -> VGPR streaming rate; with 32 rows it is MFMA-bound.
+//   16 / 32 / 64  tile form (this file): one tile per workgroup.  With 16 rows every weight fragment feeds one MFMA and the kernel is
+//             bound by the CU's L2 -> VGPR streaming rate; with 32 rows it is MFMA-bound; 64 rows (round 4) halve the fixed cost per row
+//             again and turn launches of 1-2 partly filled rounds of 32-row tiles (12 800 rows = 1.56 rounds) into one round.
 //   128       chain form (trunk_chain.h): 4 waves x 32 rows, activations register-resident, weights through an LDS ring; one
 //             workgroup per CU, one pass over the weights per 128 rows.
-// Measured on MI355X, K = 50, us per launch (profiles/r3_plans.txt):
+// Measured on MI355X, K = 50, us per launch (profiles/r4_plans.txt):
 //     rows     3200   6400  12800  16000  32000  64000
-//     16       26.1   50.8   96.8   95.0  180.5  346
-//     32       39.7   39.7   75.0   74.8  146.6  290
-//     128     137.2  137.9  139.4  138.6  138.6  278
-// i.e. a ROUND of one workgroup per CU (256 on MI355X) costs 24.5 / 37.5 / 138.6 us; the plan with the smallest predicted launch time is taken.
-constexpr float TILE16_ROUND_US = 24.5f, TILE32_ROUND_US = 37.5f, CHAIN128_ROUND_US = 138.6f;
+//     16       26.2   50.4   96.6   95.1  181.1  348
+//     32       39.6   39.8   74.9   74.8  146.8  290
+//     64       71.2   71.5   72.4   72.1  142.2  283
+//     128     136.7  137.4  138.1  137.8  138.5  276
+// i.e. a ROUND of one workgroup per CU (256 on MI355X) costs 24.5 / 37.5 / 71.3 / 138.6 us; the plan with the smallest predicted launch time is taken.
+constexpr float TILE16_ROUND_US = 24.5f, TILE32_ROUND_US = 37.5f, TILE64_ROUND_US = 71.3f, CHAIN128_ROUND_US = 138.6f;
 static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
     // a workgroup never straddles two batches; the chain form stages cvec + tvec of <= 4 clouds per workgroup (trunk_chain.h: NCL)
     auto fits = [&](int rows) {
@@ -329,13 +337,15 @@ static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
     };
     const float inf = 1e30f;
     const int ncu = gp_num_cus();  // a round = one workgroup per CU
-    const int t16 = (nrows + 15) / 16, t32 = (nrows + 31) / 32, w128 = (nrows + 127) / 128;
+    const int t16 = (nrows + 15) / 16, t32 = (nrows + 31) / 32, t64 = (nrows + 63) / 64, w128 = (nrows + 127) / 128;
     const float c16 = fits(16) ? TILE16_ROUND_US * ((t16 + ncu - 1) / ncu) : inf;
     const float c32 = fits(32) ? TILE32_ROUND_US * ((t32 + ncu - 1) / ncu) : inf;
+    const float c64 = fits(64) && kcand >= 32 ? TILE64_ROUND_US * ((t64 + ncu - 1) / ncu) : inf;  // k >= 32: a tile's rows span <= 3 clouds
     const float c128 = fits(128) ? CHAIN128_ROUND_US * ((w128 + ncu - 1) / ncu) : inf;
     int best = 16;
     float cb = c16;
     if (c32 < cb) best = 32, cb = c32;
+    if (c64 < cb) best = 64, cb = c64;
     if (c128 < cb) best = 128, cb = c128;
     return cb < inf ? best : -1;
 }

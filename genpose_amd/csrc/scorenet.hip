@@ -511,13 +511,18 @@ int gp_score_eval_plan(int tile, int nclouds, int k, const gp_scorenet *net, con
     const int P = tile == 0 ? score_plan_rows(R, 0, k) : tile;
     hipStream_t st = (hipStream_t)s;
     if (P == 128) return gp_chain::Cfg<2>::fits(k) ? launch_eval_chain<2>(R, k, net, cvec, tvec, x, sigma_dev, mode, out, st) : GP_EINVAL;
-    if (P != 16 && P != 32) return GP_EINVAL;
+    if (P != 16 && P != 32 && P != 64) return GP_EINVAL;
     static bool attr_done = false;
     if (!attr_done) {
-        if (set_lds(score_eval_kernel<16>, trunk_lds_bytes<16>()) || set_lds(score_eval_kernel<32>, trunk_lds_bytes<32>())) return GP_ELAUNCH;
+        if (set_lds(score_eval_kernel<16>, trunk_lds_bytes<16>()) || set_lds(score_eval_kernel<32>, trunk_lds_bytes<32>()) ||
+            set_lds(score_eval_kernel<64>, trunk_lds_bytes<64>()))
+            return GP_ELAUNCH;
         attr_done = true;
     }
-    if (P == 16)
+    if (P == 64)
+        hipLaunchKernelGGL(score_eval_kernel<64>, dim3((R + 63) / 64), dim3(TrunkCfg<64>::NT), trunk_lds_bytes<64>(), st, R, k, *net, cvec, tvec, x, sigma_dev,
+                           mode, out);
+    else if (P == 16)
         hipLaunchKernelGGL(score_eval_kernel<16>, dim3((R + 15) / 16), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), st, R, k, *net, cvec, tvec, x, sigma_dev,
                            mode, out);
     else
@@ -541,7 +546,7 @@ int gp_pc_tile_rows(int ngroups, int nclouds_per_group, int k) {
 }
 
 // rows per partial sum of |score| for a plan
-static int pc_rows_per_partial(int P) { return P == 16 || P == 32 ? P : P / gp_chain::NW; }  // tile form: per workgroup; chain form: per wave
+static int pc_rows_per_partial(int P) { return P <= 64 ? P : P / gp_chain::NW; }  // tile form: per workgroup; chain form: per wave
 static int pc_rows_per_wg(int P) { return P; }
 
 int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out) {
@@ -553,7 +558,7 @@ int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k,
         if (P != 16 && P != 128) return GP_EINVAL;
     }
     if (P == 0) P = score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
-    if (P != 16 && P != 32 && P != 128) return GP_EINVAL;
+    if (P != 16 && P != 32 && P != 64 && P != 128) return GP_EINVAL;
     if (P == 128 && !gp_chain::Cfg<2>::fits(k)) return GP_EINVAL;
     if (ngroups > 1 && rg % pc_rows_per_wg(P) != 0) return GP_EINVAL;  // a workgroup must not straddle two batches
     const int rpp = pc_rows_per_partial(P);
@@ -587,6 +592,7 @@ int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int
     static bool attr_done = false;
     if (!attr_done) {
         if (set_lds(pc_step_kernel<16, 0>, trunk_lds_bytes<16>()) || set_lds(pc_step_kernel<32, 0>, trunk_lds_bytes<32>()) ||
+            set_lds(pc_step_kernel<64, 0>, trunk_lds_bytes<64>()) ||
             set_lds(pc_step_kernel<16, 1>, gp_bwd::LDS_BYTES))
             return GP_ELAUNCH;
         attr_done = true;
@@ -595,6 +601,8 @@ int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int
         hipLaunchKernelGGL((pc_step_kernel<16, 1>), dim3(nwg), dim3(TrunkCfg<16>::NT), gp_bwd::LDS_BYTES, st, a, *net);
     else if (P == 16)
         hipLaunchKernelGGL((pc_step_kernel<16, 0>), dim3(nwg), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), st, a, *net);
+    else if (P == 64)
+        hipLaunchKernelGGL((pc_step_kernel<64, 0>), dim3(nwg), dim3(TrunkCfg<64>::NT), trunk_lds_bytes<64>(), st, a, *net);
     else
         hipLaunchKernelGGL((pc_step_kernel<32, 0>), dim3(nwg), dim3(TrunkCfg<32>::NT), trunk_lds_bytes<32>(), st, a, *net);
     return gp_launch_status();

@@ -46,7 +46,7 @@ class PCSampler:
         self.dev = torch.device(device)
         R = B * K
         self.R = R
-        # launch plan (csrc/score_trunk.h: score_plan_rows): 16 / 32 = tile form, 128 = chain form (register-resident trunk, weights
+        # launch plan (csrc/score_trunk.h: score_plan_rows): 16 / 32 / 64 = tile form, 128 = chain form (register-resident trunk, weights
         # through an LDS ring) for launches of ~32 000 rows and more; `tile` forces one (tests, measurements)
         import ctypes
         t_out, n_out = ctypes.c_int(0), ctypes.c_int(0)
@@ -54,7 +54,7 @@ class PCSampler:
             raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                              "run the batches separately")
         self.tile, self.nparts = t_out.value, n_out.value
-        self.kernel_name = (f"pc_step_kernel<{self.tile}>" if self.model == 0 else f"pc_step_kernel<{self.tile},energy>") if self.tile in (16, 32) else \
+        self.kernel_name = (f"pc_step_kernel<{self.tile}>" if self.model == 0 else f"pc_step_kernel<{self.tile},energy>") if self.tile in (16, 32, 64) else \
             ("pc_step_chain_kernel<2>" if self.model == 0 else "pc_step_chain_kernel<2,energy>")
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)
@@ -192,7 +192,7 @@ class ODESampler:
         if not self.ragged:
             # forward + backward right-hand sides (energy model, likelihood): 16-row tiles or, for large launches, the 128-row chain form
             self.tile = int(tile) if tile else _lib.lib().gp_rk45_plan_rows(self.model, groups, B // groups, K)
-            if self.tile not in (16, 32, 128) or (self.model != 0 and self.tile == 32) or (groups > 1 and (R // groups) % self.tile):
+            if self.tile not in (16, 32, 64, 128) or (self.model != 0 and self.tile in (32, 64)) or (groups > 1 and (R // groups) % self.tile):
                 raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                                  "run the batches separately")
             self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)

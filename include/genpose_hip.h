@@ -194,8 +194,8 @@ int gp_score_div(int nclouds, int k, const gp_scorenet *net, const float *cvec, 
 int gp_energy_score(int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x, const float *sigma_dev,
                     float *score, float *energy, gp_stream_t s);
 
-/* gp_score_eval with the launch plan chosen by the caller: tile = 0 (automatic, = gp_score_eval), 16 / 32 (tile form: one 16- or
- * 32-row tile per workgroup, activations through LDS), 128 (chain form: 4 waves x 32 rows per workgroup, activations
+/* gp_score_eval with the launch plan chosen by the caller: tile = 0 (automatic, = gp_score_eval), 16 / 32 / 64 (tile form: one 16-, 32-
+ * or 64-row tile per workgroup, activations through LDS), 128 (chain form: 4 waves x 32 rows per workgroup, activations
  * register-resident, weights through an LDS ring - csrc/trunk_chain.h; pays from ~32 000 rows; needs k >= 43 so that the rows of a
  * workgroup span at most 4 clouds, else GP_EINVAL). */
 int gp_score_eval_plan(int tile, int nclouds, int k, const gp_scorenet *net, const float *cvec, const float *tvec, const float *x,
@@ -234,7 +234,7 @@ int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int 
                        const float *centre, float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s);
 
 /* Launch plan of the PC sampler for (ngroups x nclouds_per_group clouds x k candidates) and a model (see gp_pc_step_plan): tile = 0 asks for the automatic choice, else
- * 16 / 32 / 128 as in gp_score_eval_plan.  *tile_out = the plan taken, *nparts_out = partial sums of |score| per step
+ * 16 / 32 / 64 / 128 as in gp_score_eval_plan.  *tile_out = the plan taken, *nparts_out = partial sums of |score| per step
  * (`partials` must hold nsteps * nparts floats: one per workgroup in the tile form, one per wave in the chain form).  GP_EINVAL when a
  * workgroup of the plan would straddle two groups. */
 int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out);
@@ -310,7 +310,7 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
  * squares to ext_sums; the caller all-reduces ext_sums (RCCL: capturable with the launches) and runs phase 11, 12 or 13 = the step
  * controller on the reduced sums (+ trajectory record).  Every shard then takes the accept / reject sequence of the unsharded batch.
  * ext_sums = NULL: the controller reduces the local partials itself (phases 11-13 are GP_EINVAL).
- * plan: rows per workgroup of the stage kernels - 16 / 32 = tile form (models 1 and 2, which need the backward pass: 16 only), 128 = the
+ * plan: rows per workgroup of the stage kernels - 16 / 32 / 64 = tile form (models 1 and 2, which need the backward pass: 16 only), 128 = the
  * chain form of the trunk (every model; k >= 43, rows_per_group % 128 == 0 when ngroups > 1); 0 = gp_rk45_plan_rows() picks.
  * partials [3][ngroups * ceil(rows_per_group / plan)]. */
 int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k);

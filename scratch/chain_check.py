@@ -18,7 +18,7 @@ from genpose_amd.scorenet import ScoreNetHIP  # noqa: E402
 from genpose_amd.sde import SIGMA_MAX, SIGMA_MIN  # noqa: E402
 from genpose_amd.weights_synth import make_state_dict  # noqa: E402
 
-PLANS = (16, 32, 128)
+PLANS = (16, 32, 64, 128)
 FLOP_ROW = 0.5335e6
 PEAK = 157.3
 
