@@ -192,8 +192,8 @@ class Pointnet2EncoderHIP:
         runs launch by launch (warm-up; a shape seen once never pays a capture), the second captures, later ones copy the clouds into the
         graph's static input and replay.  Results are the launch-by-launch pass's, bit for bit (same kernels, same order)."""
         direct = (lambda: self.forward(pts, grouping=grouping)) if grouping is not None else (lambda: self._forward_with_grouping(pts))
-        if not use_graph or not pts.is_cuda or torch.cuda.is_current_stream_capturing():
-            return direct()
+        if not use_graph or not pts.is_cuda or pts.dtype != torch.float32 or torch.cuda.is_current_stream_capturing():
+            return direct()  # (wrong device / dtype: the launch-by-launch path raises what it always raised)
         if not hasattr(self, "_pass_graphs"):
             self._pass_graphs = {}
         key = (tuple(pts.shape), id(grouping) if grouping is not None else None)
