@@ -125,19 +125,18 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 
 // Fused stage kernel.  STAGE 1..6: Runge-Kutta stage;  STAGE 0: f0 = fun(t0, y0) (+ d0,d1 partials);
 // STAGE 7: f1 = fun(t0 + h0*dir, y0 + h0*dir*f0) (+ d2 partial).
+// One stage for the workgroup's tile.  Returns false when the workgroup has nothing to do (padding workgroup, finished solve).
 template <int P, int STAGE, int MODEL>
-__global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, gp_scorenet net) {
+__device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_scorenet &net, float *lds, double *sh) {
     static_assert(MODEL == 0 || P == gp_bwd::DP, "the backward pass runs on 16-row tiles");
     using L = TrunkLds<P, OdeModel<MODEL>::BWD>;
     constexpr int NC = OdeModel<MODEL>::NC;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ double sh[8];
     const int tid = threadIdx.x;
     int grp, row0, rend;
     ode_block<P>(a, grp, row0, rend);
-    if (row0 >= rend) return;  // padding workgroup of a ragged launch (tables sized for a capacity)
+    if (row0 >= rend) return false;  // padding workgroup of a ragged launch (tables sized for a capacity)
     Rk45State *st = a.st + grp;
-    if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return;
+    if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return false;
     const size_t n = (size_t)a.nrows * NC;
     const int slot = (STAGE >= 1 && STAGE <= 6) ? STAGE : 0;
     const float *tvec = a.tvec + ((size_t)grp * 8 + slot) * HEADS;
@@ -227,6 +226,36 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, 
             if (tid == 0) a.partials[a.nblocks + blockIdx.x] = s1;
         }
     }
+    return true;
+}
+
+template <int P, int STAGE, int MODEL>
+__global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, gp_scorenet net) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double sh[8];
+    rk45_stage_body<P, STAGE, MODEL>(a, net, lds, sh);
+}
+
+// The six stages of an attempt in ONE launch, for the latency regime (16-row tiles: a tracking frame's solve is ~40 stage launches of
+// 17 us each on 16 of the 256 CUs, a configs[0] solve one workgroup - five launch boundaries per attempt are pure overhead there).
+// Everything a stage reads from earlier stages of the attempt is row-local: K_q of the tile's own rows, written to global memory by
+// this workgroup (by other threads of it: a workgroup-scope barrier separates the stages; none of these lines was read before it was
+// written, so no stale copy can sit in the CU's vector cache).  Same arithmetic, same order: bit-identical to the six launches.
+template <int P, int MODEL>
+__global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_attempt_kernel(OdeArgs a, gp_scorenet net) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double sh[8];
+    if (!rk45_stage_body<P, 1, MODEL>(a, net, lds, sh)) return;  // (wave-uniform: the whole workgroup leaves together)
+    __syncthreads();
+    rk45_stage_body<P, 2, MODEL>(a, net, lds, sh);
+    __syncthreads();
+    rk45_stage_body<P, 3, MODEL>(a, net, lds, sh);
+    __syncthreads();
+    rk45_stage_body<P, 4, MODEL>(a, net, lds, sh);
+    __syncthreads();
+    rk45_stage_body<P, 5, MODEL>(a, net, lds, sh);
+    __syncthreads();
+    rk45_stage_body<P, 6, MODEL>(a, net, lds, sh);
 }
 
 // The same stage in the CHAIN form of the trunk (trunk_chain.h; score model, equal groups, launches of ~32 000 rows and more): a wave
@@ -743,6 +772,9 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
         if constexpr (MODEL != 2) {
             if (set_lds_attr(rk45_finish_kernel<P, MODEL>, lds)) return GP_ELAUNCH;
         }
+        if constexpr (!CHAIN && P == 16) {
+            if (set_lds_attr(rk45_attempt_kernel<P, MODEL>, lds)) return GP_ELAUNCH;
+        }
         attr_done = true;
     }
     const dim3 grid(a.nblocks), blk(TrunkCfg<P>::NT), blk1(256);
@@ -796,12 +828,17 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             embed(1, 6);
             break;
         case 3:
-            stage(std::integral_constant<int, 1>{});
-            stage(std::integral_constant<int, 2>{});
-            stage(std::integral_constant<int, 3>{});
-            stage(std::integral_constant<int, 4>{});
-            stage(std::integral_constant<int, 5>{});
-            stage(std::integral_constant<int, 6>{});
+            if constexpr (!CHAIN && P == 16) {
+                // latency regime: the six stages of the attempt as ONE launch (rk45_attempt_kernel)
+                hipLaunchKernelGGL((rk45_attempt_kernel<P, MODEL>), grid, blk, lds, st, a, *net);
+            } else {
+                stage(std::integral_constant<int, 1>{});
+                stage(std::integral_constant<int, 2>{});
+                stage(std::integral_constant<int, 3>{});
+                stage(std::integral_constant<int, 4>{});
+                stage(std::integral_constant<int, 5>{});
+                stage(std::integral_constant<int, 6>{});
+            }
             if (a.ext_sums) {
                 hipLaunchKernelGGL(rk45_group_sums_kernel, dim3(a.ngroups), blk1, 0, st, a, 1);
                 break;
