@@ -72,6 +72,8 @@ SIGNATURES = {
                             + [c_int, c_int, P, P],
     "gp_time_embed_strided": [c_int, c_int, c_int64, NETP, P, P, P],
     "gp_rank_aggregate": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
+    "gp_pose9_to_rt": [c_int, c_int, P, P, P],
+    "gp_quat_trans_to_rt": [c_int, P, P, P],
 }
 OPTIONAL = set()
 

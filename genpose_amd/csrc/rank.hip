@@ -162,7 +162,54 @@ __global__ __launch_bounds__(64) void rank_aggregate_kernel(int k, int sel, cons
 
 }  // namespace
 
+// [n][9] poses (two rotation columns + translation) -> [n][4][4] f64 homogeneous matrices (evaluation_single.py:325-332: get_rot_matrix
+// on float64 rows, translation in the last column)
+template <typename T>
+__global__ void pose9_to_rt_kernel(int n, const T *__restrict__ pose, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double R[3][3];
+    rot6_to_matrix<T>(pose + (size_t)i * 9, R);
+    double *o = out + (size_t)i * 16;
+    for (int r = 0; r < 3; ++r) {
+        o[4 * r + 0] = R[r][0], o[4 * r + 1] = R[r][1], o[4 * r + 2] = R[r][2];
+        o[4 * r + 3] = (double)pose[(size_t)i * 9 + 6 + r];
+    }
+    o[12] = o[13] = o[14] = 0.0, o[15] = 1.0;
+}
+
+// [n][7] (w, x, y, z, t) f32 -> [n][4][4] f32: pytorch3d quaternion_to_matrix (two_s = 2 / |q|^2) + the translation
+__global__ void quat_trans_to_rt_kernel(int n, const float *__restrict__ qt, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *q = qt + (size_t)i * 7;
+    const float r = q[0], a = q[1], b = q[2], c = q[3];
+    const float two_s = 2.0f / (((r * r + a * a) + b * b) + c * c);
+    float *o = out + (size_t)i * 16;
+    o[0] = 1.f - two_s * (b * b + c * c), o[1] = two_s * (a * b - c * r), o[2] = two_s * (a * c + b * r), o[3] = q[4];
+    o[4] = two_s * (a * b + c * r), o[5] = 1.f - two_s * (a * a + c * c), o[6] = two_s * (b * c - a * r), o[7] = q[5];
+    o[8] = two_s * (a * c - b * r), o[9] = two_s * (b * c + a * r), o[10] = 1.f - two_s * (a * a + b * b), o[11] = q[6];
+    o[12] = o[13] = o[14] = 0.f, o[15] = 1.f;
+}
+
 extern "C" {
+
+int gp_pose9_to_rt(int n, int is_f64, const void *pose, double *out, gp_stream_t s) {
+    if (n < 0 || !pose || !out) return GP_EINVAL;
+    if (n == 0) return GP_OK;
+    if (is_f64)
+        hipLaunchKernelGGL(pose9_to_rt_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, n, (const double *)pose, out);
+    else
+        hipLaunchKernelGGL(pose9_to_rt_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, n, (const float *)pose, out);
+    return gp_launch_status();
+}
+
+int gp_quat_trans_to_rt(int n, const float *quat_trans, float *out, gp_stream_t s) {
+    if (n < 0 || !quat_trans || !out) return GP_EINVAL;
+    if (n == 0) return GP_OK;
+    hipLaunchKernelGGL(quat_trans_to_rt_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, n, quat_trans, out);
+    return gp_launch_status();
+}
 
 int gp_rank_aggregate(int b, int k, int sel, int is_f64, const void *poses, const float *energy, void *sorted_poses, float *sorted_energy,
                       int32_t *order, float *avg_pose, gp_stream_t s) {

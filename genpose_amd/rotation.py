@@ -52,8 +52,14 @@ def average_quaternion_batch(Q):
 
 
 def pose9_to_RT(pose):
-    """[...,9] -> [...,4,4] float64 (evaluation_single.py:325-332)"""
+    """[...,9] -> [...,4,4] float64 (evaluation_single.py:325-332).  Device tensors: one launch (gp_pose9_to_rt); host tensors: torch."""
     sh = pose.shape[:-1]
+    if pose.is_cuda and pose.dtype in (torch.float32, torch.float64):
+        from . import _lib
+        p = pose.reshape(-1, 9).contiguous()
+        out = torch.empty(p.shape[0], 4, 4, dtype=torch.float64, device=pose.device)
+        _lib.call("gp_pose9_to_rt", p.shape[0], 1 if p.dtype == torch.float64 else 0, _lib.ptr(p), _lib.ptr(out), _lib.stream_ptr())
+        return out.reshape(sh + (4, 4))
     p = pose.reshape(-1, 9).double()
     RT = torch.eye(4, dtype=torch.float64, device=pose.device).repeat(p.shape[0], 1, 1)
     RT[:, :3, :3] = get_rot_matrix(p[:, :6])
@@ -62,7 +68,13 @@ def pose9_to_RT(pose):
 
 
 def quat_trans_to_RT(avg):
-    """[B,7] (w,x,y,z,t) -> [B,4,4]"""
+    """[B,7] (w,x,y,z,t) -> [B,4,4].  float32 device tensors: one launch (gp_quat_trans_to_rt); anything else: torch."""
+    if avg.is_cuda and avg.dtype == torch.float32:
+        from . import _lib
+        a = avg.contiguous()
+        out = torch.empty(a.shape[0], 4, 4, dtype=torch.float32, device=avg.device)
+        _lib.call("gp_quat_trans_to_rt", a.shape[0], _lib.ptr(a), _lib.ptr(out), _lib.stream_ptr())
+        return out
     RT = torch.eye(4, dtype=avg.dtype, device=avg.device).repeat(avg.shape[0], 1, 1)
     RT[:, :3, :3] = quaternion_to_matrix(avg[:, :4])
     RT[:, :3, 3] = avg[:, 4:]

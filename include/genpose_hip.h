@@ -337,6 +337,13 @@ int gp_rk45_set_dense_grouped(int ngroups, void *state, const double *t_eval_dev
 int gp_rank_aggregate(int b, int k, int sel, int is_f64, const void *poses, const float *energy, void *sorted_poses,
                       float *sorted_energy, int32_t *order, float *avg_pose, gp_stream_t s);
 
+/* The 4x4 homogeneous matrices the runners hand on (evaluation_single.py:325-332, evaluation_tracking.py:60-77), one launch each instead of
+ * ~15 tensor operations: poses [n][9] (f32 or f64: is_f64) -> out [n][4][4] f64 (Gram-Schmidt of the two rotation columns in f64, as
+ * get_rot_matrix on float64 rows); quat_trans [n][7] f32 (w, x, y, z, t - gp_rank_aggregate's avg_pose) -> out [n][4][4] f32 (pytorch3d
+ * quaternion_to_matrix). */
+int gp_pose9_to_rt(int n, int is_f64, const void *pose, double *out, gp_stream_t s);
+int gp_quat_trans_to_rt(int n, const float *quat_trans, float *out, gp_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,3 +186,23 @@ def test_reference_error_behaviour(pn2):
         pn2.ball_query_wrapper(1, 8, 8, 0.1, 4, x.cpu(), x, torch.zeros(1, 8, 4, dtype=torch.int32, device="cuda"))
     with pytest.raises(RuntimeError):
         pn2.ball_query_wrapper(1, 8, 8, 0.1, 4, x.transpose(1, 2), x, torch.zeros(1, 8, 4, dtype=torch.int32, device="cuda"))
+
+
+def test_pose_to_RT_kernels_match_the_tensor_formulas():
+    """gp_pose9_to_rt / gp_quat_trans_to_rt (one launch each; what the runners hand on as 4x4 matrices) against the same helpers on host
+    tensors (get_rot_matrix in float64, pytorch3d's quaternion_to_matrix formula)."""
+    from genpose_amd import rotation
+    gen = torch.Generator().manual_seed(3)
+    pose = torch.randn(7, 13, 9, generator=gen, dtype=torch.float64)
+    pose[0, 0, :3] = 0.0  # a degenerate first column: F.normalize's eps path
+    for p in (pose, pose.float()):
+        got = rotation.pose9_to_RT(p.cuda())
+        ref = rotation.pose9_to_RT(p)
+        assert got.dtype == torch.float64 and got.shape == (7, 13, 4, 4)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-12 if p.dtype == torch.float64 else 1e-12)
+    qt = torch.randn(33, 7, generator=gen)
+    got = rotation.quat_trans_to_RT(qt.cuda())
+    ref = rotation.quat_trans_to_RT(qt)
+    assert got.dtype == torch.float32 and got.shape == (33, 4, 4)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6 * float(ref.abs().max()))
+    assert torch.equal(got[:, 3].cpu(), torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(33, 4))
