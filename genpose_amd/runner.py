@@ -186,7 +186,7 @@ class _FrameGraphs:
 
     def _rank_body(self, pred, centre, cvec_e):
         n, K = pred.shape[0], self.K
-        pose = pred.to(torch.float32)
+        pose = pred.to(torch.float32, copy=True)
         pose[:, :, 6:] -= centre.unsqueeze(1)  # posenet_agent.py:516: translations relative to the cloud centre
         energy = self.enet.pose_score_net.evaluate(cvec_e, K, pose.reshape(n * K, 9), self.tvec_e, self.sigma_e, "energy").reshape(n, K, 2)
         r = reward.rank_aggregate(pred, energy, selected_num=self.sel)
