@@ -35,7 +35,7 @@ for r in rows:
     if per_frame >= 10: print(f"{name:66s} calls/frame {int(r['Calls']) / 106:6.1f}  avg {float(r['AverageNs']) / 1e3:8.1f} us  per frame {per_frame:8.1f} us")
 print(f"kernel time per frame {tot:.1f} us (sum over all streams; 106 frames)")
 PY
-tail -1 $O/track_one.log >> $O/tracking_kernels.txt
+grep '^frames' $O/track_one.log | tail -1 >> $O/tracking_kernels.txt
 for B in 64 640; do
   timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc_fetch_$B -o run -- python scratch/microbench.py $B 50 > $O/pmc_fetch_$B.log 2>&1
   timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc_write_$B -o run -- python scratch/microbench.py $B 50 > $O/pmc_write_$B.log 2>&1
