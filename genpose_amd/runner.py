@@ -302,10 +302,12 @@ class MultiSequenceTracker:
         # keep replaying the same captured graphs
         self.cap_groups, self.cap_clouds = n_sequences, n_sequences * max_objects_per_frame
         self._sampler = None
+        self._prev = None  # (live sequences, their aggregated poses [objects,4,4] in step order) of the previous step
 
     def reset(self, seq=None):
         for i in (range(len(self.buffers)) if seq is None else [seq]):
             self.buffers[i] = {"model_name": [], "pred_sRT": None}
+        self._prev = None
 
     def step(self, frames, noise_draws=None, prior=None):
         """frames: one (pts [n_i,1024,3] device, model_names [n_i], gt_RT [n_i,4,4]) per sequence (None = the sequence has no
@@ -329,22 +331,27 @@ class MultiSequenceTracker:
         gt_all = torch.cat([frames[i][2].float().cpu() for i in live], dim=0)
         draws_all = None if noise_draws is None else [torch.cat([noise_draws[i][d] for i in live], dim=0) for d in range(4)]
         with _one_cpu_thread():
-            init_sRT = add_noise_to_RT(gt_all, draws=draws_all).to(dev)
-        prev, src, dst, off, row = [], [], [], 0, 0
-        for q, i in enumerate(live):
-            buf = self.buffers[i]
-            if buf["pred_sRT"] is not None:
-                for j, name in enumerate(frames[i][1]):
-                    if name in buf["model_name"]:
-                        src.append(off + buf["model_name"].index(name))
-                        dst.append(row + j)
-                prev.append(buf["pred_sRT"])
-                off += buf["pred_sRT"].shape[0]
-            row += counts[q]
-        if src:
-            init_sRT[torch.as_tensor(dst, device=dev)] = torch.cat(prev, dim=0)[torch.as_tensor(src, device=dev)].to(init_sRT.dtype)
-        init_x = init_sRT[:, :3, [0, 1, 3]].permute(0, 2, 1).reshape(B0 := init_sRT.shape[0], -1).clone()
-        init_x[:, -3:] -= centre
+            noised = add_noise_to_RT(gt_all, draws=draws_all)  # drawn every frame (evaluation_tracking.py:302), whether or not it is used
+        if self._prev is not None and self._prev[0] == live and all(list(frames[i][1]) == self.buffers[i]["model_name"] for i in live):
+            # every object of every sequence continues from the previous step, in the same order: the previous aggregated poses ARE the
+            # initial poses - nothing to upload, no index tensors (their pageable host-to-device copies wait for the stream)
+            init_sRT = self._prev[1]
+        else:
+            init_sRT = noised.to(dev)
+            prev, src, dst, off, row = [], [], [], 0, 0
+            for q, i in enumerate(live):
+                buf = self.buffers[i]
+                if buf["pred_sRT"] is not None:
+                    for j, name in enumerate(frames[i][1]):
+                        if name in buf["model_name"]:
+                            src.append(off + buf["model_name"].index(name))
+                            dst.append(row + j)
+                    prev.append(buf["pred_sRT"])
+                    off += buf["pred_sRT"].shape[0]
+                row += counts[q]
+            if src:
+                init_sRT[torch.as_tensor(dst, device=dev)] = torch.cat(prev, dim=0)[torch.as_tensor(src, device=dev)].to(init_sRT.dtype)
+        init_x = torch.cat([init_sRT[:, :3, 0], init_sRT[:, :3, 1], init_sRT[:, :3, 3] - centre], dim=1)  # [R[:,0], R[:,1], t - centre]
         # ---- score model: encoder -> warm-started ODE, one group per sequence
         shared = {"pts": pts, "pts_center": centre}
         # (launch by launch: the cloud count of a multi-sequence step changes from frame to frame and the pass is not launch-bound here)
@@ -355,7 +362,7 @@ class MultiSequenceTracker:
             pr = net._prior_to_device((B * K, 9), T=self.T0)
         else:
             pr = torch.cat([prior[i].reshape(-1, 9) for i in live], dim=0).to(dev).float()
-        x0 = init_x.unsqueeze(1).repeat(1, K, 1).reshape(B * K, 9).float() + pr
+        x0 = (pr.view(B, K, 9) + init_x.float().unsqueeze(1)).view(B * K, 9)  # samplers.py:180: init_x repeated K times + prior
         if B > self.cap_clouds:
             raise ValueError(f"{B} objects in this step exceed the capacity {self.cap_clouds} (n_sequences x max_objects_per_frame)")
         smp = self._sampler
@@ -375,7 +382,8 @@ class MultiSequenceTracker:
         for q, i in enumerate(live):
             sl = slice(lo, lo + counts[q])
             lo += counts[q]
-            self.buffers[i] = {"model_name": list(frames[i][1]), "pred_sRT": average_sRT[sl].clone()}
+            self.buffers[i] = {"model_name": list(frames[i][1]), "pred_sRT": average_sRT[sl]}  # (views of this step's own tensor)
             out[i] = {"init_x": init_x[sl], "pred_pose": pred[sl], "energy": energy[sl], "sorted_RTs": sorted_RTs[sl], "average_sRT": average_sRT[sl],
                       "nfev": int(smp.group_stats[q]["nfev"])}
+        self._prev = (live, average_sRT)
         return out
