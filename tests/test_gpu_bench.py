@@ -120,7 +120,7 @@ def test_config4_tracking_eight_ranks_on_one_device():
 def test_one_rank_on_rccl_costs_nothing():
     """GP_BENCH_FORCE_DIST=1: the N = 1 workload with the process group up on RCCL (backend 'nccl') - barrier, all-gather of every result and
     the MAX all-reduce of the block time inside the timed region.  The distributed plumbing must not cost throughput: the line stays within
-    2 % of the plain N = 1 line (measured: < 1 %; the bound leaves room for box-to-box noise)."""
+    3 % of the plain N = 1 line (measured: < 1 % in four sessions; the bound leaves room for run-to-run noise of two separate processes)."""
     common = ["--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-secondary"]
     plain = _run_raw(common)
     rccl = _run_raw(common, {"GP_BENCH_FORCE_DIST": "1"})
@@ -128,4 +128,4 @@ def test_one_rank_on_rccl_costs_nothing():
     assert plain["config"] == rccl["config"] and plain["n_gpus"] == rccl["n_gpus"] == 1
     ratio = rccl["value"] / plain["value"]
     print(f"one rank on RCCL: {rccl['value']:.0f} poses/s against {plain['value']:.0f} plain ({100 * (ratio - 1):+.2f} %)")
-    assert ratio > 0.98, (rccl["value"], plain["value"])
+    assert ratio > 0.97, (rccl["value"], plain["value"])
