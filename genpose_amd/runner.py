@@ -303,6 +303,7 @@ class MultiSequenceTracker:
         self.cap_groups, self.cap_clouds = n_sequences, n_sequences * max_objects_per_frame
         self._sampler = None
         self._prev = None  # (live sequences, their aggregated poses [objects,4,4] in step order) of the previous step
+        self.one_tensor_warm_starts = 0  # steps whose initial poses were the previous step's aggregated poses as they stood
 
     def reset(self, seq=None):
         for i in (range(len(self.buffers)) if seq is None else [seq]):
@@ -336,6 +337,7 @@ class MultiSequenceTracker:
             # every object of every sequence continues from the previous step, in the same order: the previous aggregated poses ARE the
             # initial poses - nothing to upload, no index tensors (their pageable host-to-device copies wait for the stream)
             init_sRT = self._prev[1]
+            self.one_tensor_warm_starts += 1
         else:
             init_sRT = noised.to(dev)
             prev, src, dst, off, row = [], [], [], 0, 0
