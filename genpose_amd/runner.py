@@ -314,7 +314,9 @@ class MultiSequenceTracker:
         """frames: one (pts [n_i,1024,3] device, model_names [n_i], gt_RT [n_i,4,4]) per sequence (None = the sequence has no
         frame this step).  Returns one TrackingRunner-style dict per sequence (None where there was no frame).
         prior (tests): per sequence, the prior draw [n_i*K,9] exactly as `prior_fn((n_i*K, 9), T=T0)` returns it (already scaled by
-        sigma(T0)) - it stands in for prior_fn, unlike the `prior_noise` of the pipeline predictors (standard-normal draws)."""
+        sigma(T0)) - it stands in for prior_fn, unlike the `prior_noise` of the pipeline predictors (standard-normal draws).
+        The returned tensors are slices of the step's own result tensors, and `average_sRT` is also the next step's warm start: read them,
+        clone before editing in place."""
         from .samplers import ODESampler
         net = self.score_agent.net
         net._need_weights()
