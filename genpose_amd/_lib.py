@@ -26,7 +26,14 @@ NETP = ctypes.POINTER(GpScoreNet)
 SIGNATURES = {
     "gp_version": [],
     "gp_device_arch": [ctypes.c_char_p, c_int],
+    "gp_arith_default": [],
     "gp_furthest_point_sampling": [c_int, c_int, c_int, P, P, P, P],
+    "gp_furthest_point_sampling_arith": [c_int, c_int, c_int, c_int, P, P, P, P],
+    "gp_ball_query_arith": [c_int, c_int, c_int, c_int, c_float, c_int, P, P, P, P],
+    "gp_three_nn_arith": [c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "gp_three_interpolate_arith": [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
+    "gp_fps_chain_arith": [c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), P, P, P, P, P, P, P, P],
+    "gp_ball_query_msg_arith": [c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int, P, P, P, P, P],
     "gp_gather_points": [c_int, c_int, c_int, c_int, P, P, P, P],
     "gp_gather_points_grad": [c_int, c_int, c_int, c_int, P, P, P, P],
     "gp_ball_query": [c_int, c_int, c_int, c_float, c_int, P, P, P, P],

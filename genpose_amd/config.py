@@ -3,6 +3,22 @@ with the reference's defaults.  `get_config(**overrides)` returns an argparse.Na
 reference's `cfg` object works unchanged; the reference's own namespace can be passed to PoseNet(cfg) directly."""
 import argparse
 
+# How the reference's `dx*dx + dy*dy + dz*dz` (sampling_gpu.cu:133, ball_query_gpu.cu:33, interpolate_gpu.cu:36; also the weighted sum
+# of interpolate_gpu.cu:95) is contracted into fused multiply-adds - nvcc's choice, which decides FPS / ball-query indices when two
+# distances agree to an ulp (include/genpose_hip.h GP_ARITH_*, DESIGN.md section 5).  Flipping the default is this one line (+ the
+# GP_ARITH_DEFAULT of the header for the C entry points without an `_arith` suffix; tests/test_abi_and_host.py holds the two and the
+# oracle's default together).
+DIST_ARITH_CODES = {"A": 0, "B": 1, "C": 2}
+DEFAULT_DIST_ARITH = "B"
+
+
+def dist_arith_code(arith=None):
+    a = DEFAULT_DIST_ARITH if arith is None else arith
+    if a not in DIST_ARITH_CODES:
+        raise ValueError(f"dist_arith must be one of {sorted(DIST_ARITH_CODES)}, got {a!r}")
+    return DIST_ARITH_CODES[a]
+
+
 DEFAULTS = dict(
     device="cuda", num_points=1024, pose_mode="rot_matrix", pts_encoder="pointnet2", pointnet2_params="light",
     posenet_mode="score", regression_head="Rx_Ry_and_T", sde_mode="ve", sampler_mode=["ode"], sampling_steps=None,
@@ -10,6 +26,7 @@ DEFAULTS = dict(
     pooling_mode="nearest", ranker="energy_ranker", score_model_dir="", energy_model_dir="", result_dir="", test_source="Real",
     save_video=False, is_train=False, use_pretrain=False, log_dir="debug", parallel=False, seed=0,
     # pre-processing / evaluation side (preprocess.py, evaluation.py): configs/config.py:8,72-78
+    dist_arith=DEFAULT_DIST_ARITH,  # (ours) contraction convention of the grouping operators' distances, see above
     synset_names=["bottle", "bowl", "camera", "can", "laptop", "mug"], img_size=256, max_eval_num=10000000, results_path="",
 )
 

@@ -9,8 +9,9 @@
 //    ONE barrier per selected point.  The tie rank reproduces the reference's shared-memory tree
 //    (sampling_gpu.cu:86-91,143-203): smallest bit-reversed slot wins.
 //  * ball query: one wave per centre, 64 candidates per step, ballot + prefix popcount keeps index order.
-//  * distances: the FMA chain nvcc emits for dx*dx+dy*dy+dz*dz, spelled with
-//    __fmaf_rn/__fmul_rn so hipcc cannot re-associate or re-contract it.
+//  * distances: `dx*dx + dy*dy + dz*dz` (sampling_gpu.cu:133, ball_query_gpu.cu:33, interpolate_gpu.cu:36) under one of three
+//    contraction conventions (GP_ARITH_A / _B / _C, include/genpose_hip.h) - a TEMPLATE parameter of every kernel that
+//    evaluates it (no run-time cost), spelled with __fmaf_rn/__fmul_rn/__fadd_rn so hipcc cannot re-associate or re-contract it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -19,12 +20,34 @@
 
 namespace {
 
+// a0*b0 + a1*b1 + a2*b2 under contraction convention AR (the reference's text leaves the contraction to nvcc):
+//   A  fma(a2,b2, fma(a1,b1, a0*b0))     B  fma(a2,b2, fma(a0,b0, a1*b1))  (LLVM / GCC: the first fadd fuses its left multiply)
+//   C  (a0*b0 + a1*b1) + a2*b2           (no contraction)
+template <int AR>
+__device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+    static_assert(AR == GP_ARITH_A || AR == GP_ARITH_B || AR == GP_ARITH_C, "unknown arithmetic convention");
+    if constexpr (AR == GP_ARITH_A) return __fmaf_rn(a2, b2, __fmaf_rn(a1, b1, __fmul_rn(a0, b0)));
+    if constexpr (AR == GP_ARITH_B) return __fmaf_rn(a2, b2, __fmaf_rn(a0, b0, __fmul_rn(a1, b1)));
+    return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
+}
+
+template <int AR>
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
     float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
-    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+    return dot3<AR>(dx, dx, dy, dy, dz, dz);
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// the same on the packed-f32 VALU, two points per instruction (v_pk_mul / v_pk_fma / v_pk_add: the IEEE operations of dot3<AR>, in
+// its order - identical bits; the library is built with -ffp-contract=off, so convention C's adds stay adds)
+template <int AR>
+__device__ __forceinline__ f32x2 sqnorm_pk(f32x2 dx, f32x2 dy, f32x2 dz) {
+    if constexpr (AR == GP_ARITH_A) return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+    if constexpr (AR == GP_ARITH_B) return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+    const f32x2 s = dx * dx + dy * dy;
+    return s + dz * dz;
+}
 
 // order-preserving float -> uint (total order on non-NaN floats)
 __device__ __forceinline__ uint32_t fkey(float f) {
@@ -102,7 +125,7 @@ __device__ __forceinline__ FpsRank make_rank(int n) {
 
 // One FPS pass over the n points held in LDS (sx/sy/sz) selecting m of them.
 // temp_io: optional global running-min buffer (API semantics) - read at start, written back at the end.
-template <int PPT, bool FULL = false>  // FULL: n == PPT * FPS_T exactly (no bounds checks in the hot loop)
+template <int AR, int PPT, bool FULL = false>  // FULL: n == PPT * FPS_T exactly (no bounds checks in the hot loop)
 __device__ void fps_pass(int n, int m, lds_cptr sx, lds_cptr sy, lds_cptr sz, float *temp_io,
                          int32_t *idx_out, unsigned long long (*slots)[FPS_T / 64]) {
     const int tid = threadIdx.x;
@@ -129,18 +152,17 @@ __device__ void fps_pass(int n, int m, lds_cptr sx, lds_cptr sy, lds_cptr sz, fl
         uint32_t bd = 0u, br = 0u;
         float dist[PPT];
         if constexpr (PPT % 2 == 0) {
-            // two points per instruction on the packed-f32 VALU (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE operations, in the same
-            // order, as sqdist's fmaf chain - identical bits)
+            // two points per instruction on the packed-f32 VALU (the same IEEE operations, in the same order, as sqdist<AR>)
             const f32x2 X1 = {x1, x1}, Y1 = {y1, y1}, Z1 = {z1, z1};
 #pragma unroll
             for (int j = 0; j < PPT; j += 2) {
                 const f32x2 dx = f32x2{px[j], px[j + 1]} - X1, dy = f32x2{py[j], py[j + 1]} - Y1, dz = f32x2{pz[j], pz[j + 1]} - Z1;
-                const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                const f32x2 d = sqnorm_pk<AR>(dx, dy, dz);
                 dist[j] = d.x, dist[j + 1] = d.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) dist[j] = sqdist(px[j], py[j], pz[j], x1, y1, z1);
+            for (int j = 0; j < PPT; ++j) dist[j] = sqdist<AR>(px[j], py[j], pz[j], x1, y1, z1);
         }
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -179,6 +201,7 @@ __device__ void fps_pass(int n, int m, lds_cptr sx, lds_cptr sy, lds_cptr sz, fl
 }
 
 // Fallback for n > FPS_T*FPS_MAXPPT: running min kept in global memory (temp must be provided).
+template <int AR>
 __device__ void fps_pass_big(int n, int m, const float *xyz, float *temp, int32_t *idx_out,
                              unsigned long long (*slots)[FPS_T / 64]) {
     const int tid = threadIdx.x;
@@ -189,7 +212,7 @@ __device__ void fps_pass_big(int n, int m, const float *xyz, float *temp, int32_
         float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
         uint32_t bd = 0u, br = 0u;
         for (int k = tid; k < n; k += FPS_T) {
-            float d = sqdist(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], x1, y1, z1);
+            float d = sqdist<AR>(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], x1, y1, z1);
             float d2 = fminf(d, temp[k]);
             temp[k] = d2;
             const uint32_t dk = fkey(d2), rr = rk.rank(k);
@@ -212,7 +235,7 @@ __device__ void fps_pass_big(int n, int m, const float *xyz, float *temp, int32_
     }
 }
 
-template <int PPT>
+template <int AR, int PPT>
 __global__ __launch_bounds__(FPS_T) void fps_kernel(int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
                                                     int32_t *__restrict__ idx) {
     extern __shared__ float lds[];  // sx[n] sy[n] sz[n]
@@ -228,14 +251,15 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(int n, int m, const float *_
         (c == 0 ? sx : c == 1 ? sy : sz)[k] = v;
     }
     __syncthreads();
-    fps_pass<PPT>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), temp, idx, slots);
+    fps_pass<AR, PPT>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), temp, idx, slots);
 }
 
+template <int AR>
 __global__ __launch_bounds__(FPS_T) void fps_big_kernel(int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
                                                         int32_t *__restrict__ idx) {
     __shared__ unsigned long long slots[2][FPS_T / 64];
     const int b = blockIdx.x;
-    fps_pass_big(n, m, xyz + (size_t)b * n * 3, temp + (size_t)b * n, idx + (size_t)b * m, slots);
+    fps_pass_big<AR>(n, m, xyz + (size_t)b * n * 3, temp + (size_t)b * n, idx + (size_t)b * m, slots);
 }
 
 // FPS + gather for up to three consecutive levels (encoder path): n0 <= 1024.
@@ -250,6 +274,7 @@ struct FpsChainArgs {
 // LDS (dynamic): coordinate planes A [3][n0] and B [3][m0] that the levels ping-pong between (every level is at most as large as
 // the one before, so level l+1 always fits the buffer level l-1 lived in) + the selected indices [m0]: 20.3 KB for 1024 -> 512 ->
 // 256 -> 128 - small enough to share a CU with a 135 KB score-network workgroup of another stream.
+template <int AR>
 __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
     extern __shared__ float fps_lds[];
     __shared__ unsigned long long slots[2][FPS_T / 64];
@@ -269,17 +294,17 @@ __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
         float *sx = plane[buf], *sy = plane[buf] + cap[buf], *sz = plane[buf] + 2 * cap[buf];
         float *nx = plane[buf ^ 1], *ny = plane[buf ^ 1] + cap[buf ^ 1], *nz = plane[buf ^ 1] + 2 * cap[buf ^ 1];
         if (n == 4 * FPS_T)
-            fps_pass<4, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+            fps_pass<AR, 4, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else if (n == 2 * FPS_T)
-            fps_pass<2, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+            fps_pass<AR, 2, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else if (n == FPS_T)
-            fps_pass<1, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+            fps_pass<AR, 1, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else if (n <= FPS_T)
-            fps_pass<1>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+            fps_pass<AR, 1>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else if (n <= 2 * FPS_T)
-            fps_pass<2>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+            fps_pass<AR, 2>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         else
-            fps_pass<4>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+            fps_pass<AR, 4>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
         __syncthreads();
         int32_t *gi = a.idx[l] + (size_t)b * m;
         float *gx = a.new_xyz[l] + (size_t)b * m * 3;
@@ -308,7 +333,7 @@ constexpr int BQ_T = 256;
 constexpr int BQ_CPW = 4;
 
 // One wave scans the cloud in index order, 64 candidates per step.  NS = number of scales (1 or 2).
-template <int NS, bool ZERO_FILL>
+template <int AR, int NS, bool ZERO_FILL>
 __global__ __launch_bounds__(BQ_T) void ball_query_kernel(int n, int m, float r0, int ns0, float r1, int ns1,
                                                           const float *__restrict__ new_xyz, const float *__restrict__ xyz,
                                                           int32_t *__restrict__ idx0, int32_t *__restrict__ idx1) {
@@ -335,7 +360,7 @@ __global__ __launch_bounds__(BQ_T) void ball_query_kernel(int n, int m, float r0
         for (int base = 0; base < n; base += 64) {
             const int k = base + lane;
             float d2 = 3.0e38f;
-            if (k < n) d2 = sqdist(cx, cy, cz, sx[k], sy[k], sz[k]);
+            if (k < n) d2 = sqdist<AR>(cx, cy, cz, sx[k], sy[k], sz[k]);
             if (cnt0 < ns0) {
                 unsigned long long mk = __ballot(k < n && d2 < rr0);
                 if (mk) {
@@ -369,6 +394,7 @@ __global__ __launch_bounds__(BQ_T) void ball_query_kernel(int n, int m, float r0
 }
 
 // Large-n fallback (cloud does not fit LDS): candidates straight from global memory (L1/L2 resident).
+template <int AR>
 __global__ __launch_bounds__(BQ_T) void ball_query_big_kernel(int n, int m, float r0, int ns0, const float *__restrict__ new_xyz,
                                                               const float *__restrict__ xyz, int32_t *__restrict__ idx0) {
     const int b = blockIdx.y;
@@ -385,7 +411,7 @@ __global__ __launch_bounds__(BQ_T) void ball_query_big_kernel(int n, int m, floa
     for (int base = 0; base < n && cnt0 < ns0; base += 64) {
         const int k = base + lane;
         float d2 = 3.0e38f;
-        if (k < n) d2 = sqdist(cx, cy, cz, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+        if (k < n) d2 = sqdist<AR>(cx, cy, cz, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
         unsigned long long mk = __ballot(k < n && d2 < rr0);
         if (mk) {
             if (cnt0 == 0) first0 = base + __ffsll((long long)mk) - 1;
@@ -429,6 +455,7 @@ __global__ void group_points_grad_kernel(int c, int n, int q, const float *__res
 }
 
 // ---------------------------------------------------------------------------------------------- three_nn / interpolate
+template <int AR>
 __global__ void three_nn_kernel(int n, int m, const float *__restrict__ unknown, const float *__restrict__ known,
                                 float *__restrict__ dist2, int32_t *__restrict__ idx) {
     extern __shared__ float lds[];  // kx[m] ky[m] kz[m] (tiled in chunks of TILE)
@@ -454,7 +481,7 @@ __global__ void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
         __syncthreads();
         if (p < n) {
             for (int k = 0; k < cnt; ++k) {
-                double d = (double)sqdist(ux, uy, uz, kx[k], ky[k], kz[k]);
+                double d = (double)sqdist<AR>(ux, uy, uz, kx[k], ky[k], kz[k]);
                 int kk = base + k;
                 if (d < best1) {
                     best3 = best2; b3 = b2;
@@ -477,6 +504,7 @@ __global__ void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
     }
 }
 
+template <int AR>
 __global__ void three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points, const int32_t *__restrict__ idx,
                                          const float *__restrict__ weight, float *__restrict__ out) {
     const int b = blockIdx.z, ci = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,8 +512,8 @@ __global__ void three_interpolate_kernel(int c, int m, int n, const float *__res
     const float *w = weight + ((size_t)b * n + p) * 3;
     const int32_t *id = idx + ((size_t)b * n + p) * 3;
     const float *src = points + ((size_t)b * c + ci) * m;
-    // nvcc contraction of w0*p0 + w1*p1 + w2*p2 (interpolate_gpu.cu:95)
-    out[((size_t)b * c + ci) * n + p] = __fmaf_rn(w[2], src[id[2]], __fmaf_rn(w[1], src[id[1]], __fmul_rn(w[0], src[id[0]])));
+    // w0*p0 + w1*p1 + w2*p2 (interpolate_gpu.cu:95): the same three-product sum, the same conventions
+    out[((size_t)b * c + ci) * n + p] = dot3<AR>(w[0], src[id[0]], w[1], src[id[1]], w[2], src[id[2]]);
 }
 
 __global__ void three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
@@ -506,30 +534,47 @@ __global__ void three_interpolate_grad_kernel(int c, int n, int m, const float *
 // ================================================================================================ C ABI
 extern "C" {
 
-int gp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, gp_stream_t s) {
-    if (b < 0 || n <= 0 || m < 0 || !xyz || !temp || !idx) return GP_EINVAL;
+// run `stmt` with AR = the compile-time constant of `arith` (validated by the caller)
+#define GP_ARITH_SWITCH(arith, stmt)                                              \
+    switch (arith) {                                                              \
+        case GP_ARITH_A: { constexpr int AR = GP_ARITH_A; stmt; } break;          \
+        case GP_ARITH_B: { constexpr int AR = GP_ARITH_B; stmt; } break;          \
+        default: { constexpr int AR = GP_ARITH_C; stmt; } break;                  \
+    }
+
+static bool arith_ok(int arith) { return arith == GP_ARITH_A || arith == GP_ARITH_B || arith == GP_ARITH_C; }
+
+int gp_arith_default(void) { return GP_ARITH_DEFAULT; }
+
+int gp_furthest_point_sampling_arith(int arith, int b, int n, int m, const float *xyz, float *temp, int32_t *idx, gp_stream_t s) {
+    if (!arith_ok(arith) || b < 0 || n <= 0 || m < 0 || !xyz || !temp || !idx) return GP_EINVAL;
     if (b == 0 || m == 0) return GP_OK;
     if (m > n) return GP_EINVAL;
     hipStream_t st = (hipStream_t)s;
     const size_t lds = (size_t)n * 3 * sizeof(float);
-    if (n <= FPS_T)
-        hipLaunchKernelGGL(fps_kernel<1>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
-    else if (n <= 2 * FPS_T)
-        hipLaunchKernelGGL(fps_kernel<2>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
-    else if (n <= 4 * FPS_T)
-        hipLaunchKernelGGL(fps_kernel<4>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
-    else if (n <= 8 * FPS_T)
-        hipLaunchKernelGGL(fps_kernel<8>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
-    else if (n <= FPS_MAXPPT * FPS_T)
-        hipLaunchKernelGGL(fps_kernel<FPS_MAXPPT>, dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
-    else
-        hipLaunchKernelGGL(fps_big_kernel, dim3(b), dim3(FPS_T), 0, st, n, m, xyz, temp, idx);
+    GP_ARITH_SWITCH(arith, {
+        if (n <= FPS_T)
+            hipLaunchKernelGGL((fps_kernel<AR, 1>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+        else if (n <= 2 * FPS_T)
+            hipLaunchKernelGGL((fps_kernel<AR, 2>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+        else if (n <= 4 * FPS_T)
+            hipLaunchKernelGGL((fps_kernel<AR, 4>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+        else if (n <= 8 * FPS_T)
+            hipLaunchKernelGGL((fps_kernel<AR, 8>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+        else if (n <= FPS_MAXPPT * FPS_T)
+            hipLaunchKernelGGL((fps_kernel<AR, FPS_MAXPPT>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+        else
+            hipLaunchKernelGGL((fps_big_kernel<AR>), dim3(b), dim3(FPS_T), 0, st, n, m, xyz, temp, idx);
+    })
     return gp_launch_status();
 }
+int gp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, gp_stream_t s) {
+    return gp_furthest_point_sampling_arith(GP_ARITH_DEFAULT, b, n, m, xyz, temp, idx, s);
+}
 
-int gp_fps_chain(int b, int n0, int nlevels, const int *m, const float *xyz, int32_t *idx0, float *new_xyz0, int32_t *idx1,
-                 float *new_xyz1, int32_t *idx2, float *new_xyz2, gp_stream_t s) {
-    if (b < 0 || n0 <= 0 || n0 > 1024 || nlevels < 1 || nlevels > 3 || !m || !xyz) return GP_EINVAL;
+int gp_fps_chain_arith(int arith, int b, int n0, int nlevels, const int *m, const float *xyz, int32_t *idx0, float *new_xyz0, int32_t *idx1,
+                       float *new_xyz1, int32_t *idx2, float *new_xyz2, gp_stream_t s) {
+    if (!arith_ok(arith) || b < 0 || n0 <= 0 || n0 > 1024 || nlevels < 1 || nlevels > 3 || !m || !xyz) return GP_EINVAL;
     if (b == 0) return GP_OK;
     FpsChainArgs a;
     a.n0 = n0;
@@ -548,34 +593,46 @@ int gp_fps_chain(int b, int n0, int nlevels, const int *m, const float *xyz, int
         }
     }
     const size_t lds = ((size_t)3 * n0 + 4 * (size_t)a.m[0]) * sizeof(float);
-    hipLaunchKernelGGL(fps_chain_kernel, dim3(b), dim3(FPS_T), lds, (hipStream_t)s, a);
+    GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((fps_chain_kernel<AR>), dim3(b), dim3(FPS_T), lds, (hipStream_t)s, a))
     return gp_launch_status();
 }
+int gp_fps_chain(int b, int n0, int nlevels, const int *m, const float *xyz, int32_t *idx0, float *new_xyz0, int32_t *idx1,
+                 float *new_xyz1, int32_t *idx2, float *new_xyz2, gp_stream_t s) {
+    return gp_fps_chain_arith(GP_ARITH_DEFAULT, b, n0, nlevels, m, xyz, idx0, new_xyz0, idx1, new_xyz1, idx2, new_xyz2, s);
+}
 
-int gp_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx, gp_stream_t s) {
-    if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || !new_xyz || !xyz || !idx) return GP_EINVAL;
+int gp_ball_query_arith(int arith, int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx,
+                        gp_stream_t s) {
+    if (!arith_ok(arith) || b < 0 || n <= 0 || m < 0 || nsample <= 0 || !new_xyz || !xyz || !idx) return GP_EINVAL;
     if (b == 0 || m == 0) return GP_OK;
     hipStream_t st = (hipStream_t)s;
     if ((size_t)n * 12 <= 60 * 1024) {
         dim3 grid((m + (BQ_T / 64) * BQ_CPW - 1) / ((BQ_T / 64) * BQ_CPW), b);
-        hipLaunchKernelGGL((ball_query_kernel<1, false>), grid, dim3(BQ_T), (size_t)n * 12, st, n, m, radius, nsample, 0.f, 0, new_xyz,
-                           xyz, idx, (int32_t *)nullptr);
+        GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((ball_query_kernel<AR, 1, false>), grid, dim3(BQ_T), (size_t)n * 12, st, n, m, radius, nsample,
+                                                  0.f, 0, new_xyz, xyz, idx, (int32_t *)nullptr))
     } else {
         dim3 grid((m + BQ_T / 64 - 1) / (BQ_T / 64), b);
-        hipLaunchKernelGGL(ball_query_big_kernel, grid, dim3(BQ_T), 0, st, n, m, radius, nsample, new_xyz, xyz, idx);
+        GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((ball_query_big_kernel<AR>), grid, dim3(BQ_T), 0, st, n, m, radius, nsample, new_xyz, xyz, idx))
     }
     return gp_launch_status();
 }
+int gp_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx, gp_stream_t s) {
+    return gp_ball_query_arith(GP_ARITH_DEFAULT, b, n, m, radius, nsample, new_xyz, xyz, idx, s);
+}
 
-int gp_ball_query_msg(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
-                      const float *xyz, int32_t *idx0, int32_t *idx1, gp_stream_t s) {
-    if (b < 0 || n <= 0 || m < 0 || nsample0 <= 0 || nsample1 <= 0 || !new_xyz || !xyz || !idx0 || !idx1) return GP_EINVAL;
+int gp_ball_query_msg_arith(int arith, int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
+                            const float *xyz, int32_t *idx0, int32_t *idx1, gp_stream_t s) {
+    if (!arith_ok(arith) || b < 0 || n <= 0 || m < 0 || nsample0 <= 0 || nsample1 <= 0 || !new_xyz || !xyz || !idx0 || !idx1) return GP_EINVAL;
     if ((size_t)n * 12 > 60 * 1024) return GP_EINVAL;
     if (b == 0 || m == 0) return GP_OK;
     dim3 grid((m + (BQ_T / 64) * BQ_CPW - 1) / ((BQ_T / 64) * BQ_CPW), b);
-    hipLaunchKernelGGL((ball_query_kernel<2, true>), grid, dim3(BQ_T), (size_t)n * 12, (hipStream_t)s, n, m, radius0, nsample0, radius1,
-                       nsample1, new_xyz, xyz, idx0, idx1);
+    GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((ball_query_kernel<AR, 2, true>), grid, dim3(BQ_T), (size_t)n * 12, (hipStream_t)s, n, m, radius0,
+                                              nsample0, radius1, nsample1, new_xyz, xyz, idx0, idx1))
     return gp_launch_status();
+}
+int gp_ball_query_msg(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
+                      const float *xyz, int32_t *idx0, int32_t *idx1, gp_stream_t s) {
+    return gp_ball_query_msg_arith(GP_ARITH_DEFAULT, b, n, m, radius0, nsample0, radius1, nsample1, new_xyz, xyz, idx0, idx1, s);
 }
 
 int gp_gather_points(int b, int c, int n, int m, const float *points, const int32_t *idx, float *out, gp_stream_t s) {
@@ -615,22 +672,29 @@ int gp_group_points_grad(int b, int c, int n, int npoints, int nsample, const fl
     return gp_launch_status();
 }
 
-int gp_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, gp_stream_t s) {
-    if (b < 0 || n < 0 || m <= 0 || !unknown || !known || !dist2 || !idx) return GP_EINVAL;
+int gp_three_nn_arith(int arith, int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, gp_stream_t s) {
+    if (!arith_ok(arith) || b < 0 || n < 0 || m <= 0 || !unknown || !known || !dist2 || !idx) return GP_EINVAL;
     if (b == 0 || n == 0) return GP_OK;
-    hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 3 * 2048 * sizeof(float), (hipStream_t)s, n, m, unknown, known,
-                       dist2, idx);
+    GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((three_nn_kernel<AR>), dim3((n + 255) / 256, b), dim3(256), 3 * 2048 * sizeof(float), (hipStream_t)s,
+                                              n, m, unknown, known, dist2, idx))
     return gp_launch_status();
 }
+int gp_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, gp_stream_t s) {
+    return gp_three_nn_arith(GP_ARITH_DEFAULT, b, n, m, unknown, known, dist2, idx, s);
+}
 
-int gp_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out,
-                         gp_stream_t s) {
-    if (b < 0 || c < 0 || m <= 0 || n < 0 || !points || !idx || !weight || !out) return GP_EINVAL;
+int gp_three_interpolate_arith(int arith, int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out,
+                               gp_stream_t s) {
+    if (!arith_ok(arith) || b < 0 || c < 0 || m <= 0 || n < 0 || !points || !idx || !weight || !out) return GP_EINVAL;
     if (b == 0 || c == 0 || n == 0) return GP_OK;
     if (c > 65535 || b > 65535) return GP_EINVAL;
-    hipLaunchKernelGGL(three_interpolate_kernel, dim3((n + 255) / 256, c, b), dim3(256), 0, (hipStream_t)s, c, m, n, points, idx, weight,
-                       out);
+    GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((three_interpolate_kernel<AR>), dim3((n + 255) / 256, c, b), dim3(256), 0, (hipStream_t)s, c, m, n,
+                                              points, idx, weight, out))
     return gp_launch_status();
+}
+int gp_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out,
+                         gp_stream_t s) {
+    return gp_three_interpolate_arith(GP_ARITH_DEFAULT, b, c, m, n, points, idx, weight, out, s);
 }
 
 int gp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx, const float *weight,

@@ -18,6 +18,7 @@ import torch
 
 from . import _lib
 from ._lib import ptr, stream_ptr
+from .config import dist_arith_code
 from .weights import EncoderWeights
 
 
@@ -25,8 +26,11 @@ _GENERATION = itertools.count(1)  # process-wide: every write of a workspace's g
 
 
 class Pointnet2EncoderHIP:
-    def __init__(self, state_dict, device="cuda", params="light", prefix="pts_encoder."):
+    def __init__(self, state_dict, device="cuda", params="light", prefix="pts_encoder.", arith=None):
+        """arith: contraction convention of the squared distances in furthest point sampling and the ball queries ('A' | 'B' | 'C',
+        config.DEFAULT_DIST_ARITH when None; include/genpose_hip.h GP_ARITH_*)."""
         self.device = torch.device(device)
+        self.arith = dist_arith_code(arith)
         self.w = EncoderWeights(state_dict, self.device, params, prefix)
         self.cfg = self.w.cfg
         self.out_dim = self.w.out_dim
@@ -77,13 +81,13 @@ class Pointnet2EncoderHIP:
             m = (ctypes.c_int * 3)(*([cfg["npoints"][k] for k in group_levels] + [0] * (3 - len(group_levels))))
             pi = [ptr(ws["fps_idx"][l]) if l < len(group_levels) else None for l in range(3)]
             px = [ptr(ws["new_xyz"][l]) if l < len(group_levels) else None for l in range(3)]
-            _lib.call("gp_fps_chain", B, N, len(group_levels), m, ptr(xyz0), pi[0], px[0], pi[1], px[1], pi[2], px[2], st)
+            _lib.call("gp_fps_chain_arith", self.arith, B, N, len(group_levels), m, ptr(xyz0), pi[0], px[0], pi[1], px[1], pi[2], px[2], st)
         else:
             cur = xyz0
             for l, k in enumerate(group_levels):
                 npnt = cfg["npoints"][k]
                 temp = torch.full((B, cur.shape[1]), 1e10, device=self.device)
-                _lib.call("gp_furthest_point_sampling", B, cur.shape[1], npnt, ptr(cur), ptr(temp), ptr(ws["fps_idx"][l]), st)
+                _lib.call("gp_furthest_point_sampling_arith", self.arith, B, cur.shape[1], npnt, ptr(cur), ptr(temp), ptr(ws["fps_idx"][l]), st)
                 torch.gather(cur, 1, ws["fps_idx"][l].long().unsqueeze(-1).expand(B, npnt, 3), out=ws["new_xyz"][l])
                 cur = ws["new_xyz"][l]
         return xyz0
@@ -103,18 +107,18 @@ class Pointnet2EncoderHIP:
                 continue
             radii, nss = cfg["radii"][k], cfg["nsamples"][k]
             if len(self.w.levels[k]) == 2:
-                _lib.call("gp_ball_query_msg", B, n, npnt, float(radii[0]), nss[0], float(radii[1]), nss[1], ptr(new_xyz), ptr(xyz),
+                _lib.call("gp_ball_query_msg_arith", self.arith, B, n, npnt, float(radii[0]), nss[0], float(radii[1]), nss[1], ptr(new_xyz), ptr(xyz),
                           ptr(ws["bq"][k][0]), ptr(ws["bq"][k][1]), st)
             else:
                 for i in range(len(self.w.levels[k])):
                     ws["bq"][k][i].zero_()
-                    _lib.call("gp_ball_query", B, n, npnt, float(radii[i]), nss[i], ptr(new_xyz), ptr(xyz), ptr(ws["bq"][k][i]), st)
+                    _lib.call("gp_ball_query_arith", self.arith, B, n, npnt, float(radii[i]), nss[i], ptr(new_xyz), ptr(xyz), ptr(ws["bq"][k][i]), st)
             xyz, n = new_xyz, npnt
 
     def grouping_key(self):
         """Everything the sampled centres and neighbourhoods depend on besides the coordinates."""
         c = self.cfg
-        return (tuple(c["npoints"]), tuple(map(tuple, c["radii"])), tuple(map(tuple, c["nsamples"])))
+        return (tuple(c["npoints"]), tuple(map(tuple, c["radii"])), tuple(map(tuple, c["nsamples"])), self.arith)
 
     def prepare_grouping(self, pts, slot=0, defer_join=False):
         """Furthest point sampling + gather + ball queries for every level into workspace `slot`; returns that workspace.  These
@@ -149,7 +153,7 @@ class Pointnet2EncoderHIP:
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(self.device)
         m0 = (ctypes.c_int * 3)(cfg["npoints"][group_levels[0]], 0, 0)
-        _lib.call("gp_fps_chain", B, N, 1, m0, ptr(xyz0), ptr(ws["fps_idx"][0]), ptr(ws["new_xyz"][0]), None, None, None, None, stream_ptr())
+        _lib.call("gp_fps_chain_arith", self.arith, B, N, 1, m0, ptr(xyz0), ptr(ws["fps_idx"][0]), ptr(ws["new_xyz"][0]), None, None, None, None, stream_ptr())
         fork = torch.cuda.Event()
         fork.record(cur)
         with torch.cuda.stream(self._side):
@@ -159,7 +163,7 @@ class Pointnet2EncoderHIP:
             pi = [ptr(ws["fps_idx"][l + 1]) if l < len(rest) else None for l in range(2)]
             px = [ptr(ws["new_xyz"][l + 1]) if l < len(rest) else None for l in range(2)]
             # the deeper levels select among level 0's centres, in their order: the same chain, started from new_xyz[0]
-            _lib.call("gp_fps_chain", B, cfg["npoints"][group_levels[0]], len(rest), mr, ptr(ws["new_xyz"][0]), pi[0], px[0], pi[1], px[1], None, None,
+            _lib.call("gp_fps_chain_arith", self.arith, B, cfg["npoints"][group_levels[0]], len(rest), mr, ptr(ws["new_xyz"][0]), pi[0], px[0], pi[1], px[1], None, None,
                       stream_ptr())
             self._ball_queries(ws, xyz0, B, N, levels=set(rest))
             join = torch.cuda.Event()

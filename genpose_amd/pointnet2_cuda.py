@@ -13,6 +13,17 @@ import torch
 
 from . import _lib
 from ._lib import ptr, stream_ptr
+from .config import DEFAULT_DIST_ARITH, dist_arith_code
+
+# Contraction convention of the three-product sums in furthest point sampling, ball query, three-NN and three-interpolate
+# ('A' | 'B' | 'C', include/genpose_hip.h GP_ARITH_*).  The reference's nine signatures have no room for it: it is module state.
+ARITH = DEFAULT_DIST_ARITH
+
+
+def set_arith(arith):
+    global ARITH
+    dist_arith_code(arith)
+    ARITH = arith
 
 
 def _chk(*tensors):
@@ -38,7 +49,7 @@ def _i32(*ts):
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     _chk(new_xyz, xyz, idx); _f32(new_xyz, xyz); _i32(idx)
     _lib.check_device()
-    _lib.call("gp_ball_query", b, n, m, float(radius), nsample, ptr(new_xyz), ptr(xyz), ptr(idx), stream_ptr())
+    _lib.call("gp_ball_query_arith", dist_arith_code(ARITH), b, n, m, float(radius), nsample, ptr(new_xyz), ptr(xyz), ptr(idx), stream_ptr())
     return 1
 
 
@@ -73,21 +84,21 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     _chk(points, temp, idx); _f32(points, temp); _i32(idx)
     _lib.check_device()
-    _lib.call("gp_furthest_point_sampling", b, n, m, ptr(points), ptr(temp), ptr(idx), stream_ptr())
+    _lib.call("gp_furthest_point_sampling_arith", dist_arith_code(ARITH), b, n, m, ptr(points), ptr(temp), ptr(idx), stream_ptr())
     return 1
 
 
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     _chk(unknown, known, dist2, idx); _f32(unknown, known, dist2); _i32(idx)
     _lib.check_device()
-    _lib.call("gp_three_nn", b, n, m, ptr(unknown), ptr(known), ptr(dist2), ptr(idx), stream_ptr())
+    _lib.call("gp_three_nn_arith", dist_arith_code(ARITH), b, n, m, ptr(unknown), ptr(known), ptr(dist2), ptr(idx), stream_ptr())
     return 1
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     _chk(points, idx, weight, out); _f32(points, weight, out); _i32(idx)
     _lib.check_device()
-    _lib.call("gp_three_interpolate", b, c, m, n, ptr(points), ptr(idx), ptr(weight), ptr(out), stream_ptr())
+    _lib.call("gp_three_interpolate_arith", dist_arith_code(ARITH), b, c, m, n, ptr(points), ptr(idx), ptr(weight), ptr(out), stream_ptr())
 
 
 def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):

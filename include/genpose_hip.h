@@ -33,6 +33,25 @@ extern "C" {
 typedef void *gp_stream_t; /* hipStream_t */
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Arithmetic convention of the reference's three-product sums.  The reference's kernels say
+ *     d = dx*dx + dy*dy + dz*dz          sampling_gpu.cu:133, ball_query_gpu.cu:33, interpolate_gpu.cu:36
+ *     o = w0*p0 + w1*p1 + w2*p2          interpolate_gpu.cu:95
+ * and are built with plain `nvcc -O2` (setup.py:19-20: --fmad=true), so nvcc decides how they contract - and which product
+ * is fused decides, for distances that agree to an ulp, WHICH index furthest point sampling or a ball query returns.  There is
+ * no CUDA toolchain here to settle it, so the convention is an explicit, tested parameter (compile-time inside every kernel):
+ *     GP_ARITH_A   fma(c,c, fma(b,b, a*a))   the first product rounded on its own, the other two fused left to right
+ *     GP_ARITH_B   fma(c,c, fma(a,a, b*b))   what LLVM's DAG combiner and GCC's widening-mul pass emit for this text: the
+ *                                            inner fadd fuses its LEFT operand's multiply, the outer one the remaining product
+ *     GP_ARITH_C   (a*a + b*b) + c*c         no contraction (nvcc --fmad=false)
+ * GP_ARITH_DEFAULT is what every entry point WITHOUT an `_arith` suffix uses (DESIGN.md section 5 has the evidence and the
+ * measured index differences between the conventions); the `_arith` twin of an entry point takes the convention first. */
+#define GP_ARITH_A 0
+#define GP_ARITH_B 1
+#define GP_ARITH_C 2
+#define GP_ARITH_DEFAULT GP_ARITH_B
+int gp_arith_default(void); /* the GP_ARITH_DEFAULT this library was built with */
+
+/* ---------------------------------------------------------------------------------------------------------------
  * E. Depth + instance mask -> point clouds (the step right before the path).
  * Replaces the per-detection body of detect_mrcnn_genpose (runners/evaluation_single.py:162-216):
  *   crop_resize_by_warp_affine(INTER_NEAREST) of raw depth, mask & (depth > 0) and the pixel-coordinate map
@@ -60,6 +79,7 @@ int gp_device_arch(char *buf, int buflen);
  * xyz [b,n,3] f32; temp [b,n] f32 in/out (caller fills 1e10, pointnet2_utils.py:27; must be >= 0);
  * idx [b,m] i32 out.  idx[:,0] = 0; ties resolved exactly as the reference's shared-memory tree does. */
 int gp_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, gp_stream_t s);
+int gp_furthest_point_sampling_arith(int arith, int b, int n, int m, const float *xyz, float *temp, int32_t *idx, gp_stream_t s);
 
 /* gather_points_wrapper (sampling.cpp:13-23, sampling_gpu.cu:8-44): points [b,c,n], idx [b,m] -> out [b,c,m]. */
 int gp_gather_points(int b, int c, int n, int m, const float *points, const int32_t *idx, float *out, gp_stream_t s);
@@ -71,6 +91,8 @@ int gp_gather_points_grad(int b, int c, int n, int m, const float *grad_out, con
  * d2 < radius^2 (strict, radius^2 in f32); the first hit pre-fills every slot; rows with no hit are
  * left untouched (caller pre-zeroes idx, pointnet2_utils.py:219). */
 int gp_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx, gp_stream_t s);
+int gp_ball_query_arith(int arith, int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx,
+                        gp_stream_t s);
 
 /* group_points_wrapper (group_points.cpp:26-37, group_points_gpu.cu:47-86): points [b,c,n], idx [b,np,ns] -> out [b,c,np,ns]. */
 int gp_group_points(int b, int c, int n, int npoints, int nsample, const float *points, const int32_t *idx, float *out, gp_stream_t s);
@@ -79,8 +101,11 @@ int gp_group_points_grad(int b, int c, int n, int npoints, int nsample, const fl
 
 /* three_nn_wrapper (interpolate.cpp, interpolate_gpu.cu:9-74): unknown [b,n,3], known [b,m,3] -> dist2 [b,n,3] f32, idx [b,n,3] i32. */
 int gp_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, gp_stream_t s);
+int gp_three_nn_arith(int arith, int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, gp_stream_t s);
 /* three_interpolate_wrapper (interpolate_gpu.cu:77-117): points [b,c,m], idx/weight [b,n,3] -> out [b,c,n]. */
 int gp_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out, gp_stream_t s);
+int gp_three_interpolate_arith(int arith, int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out,
+                               gp_stream_t s);
 /* three_interpolate_grad_wrapper (interpolate_gpu.cu:120-160): grad_out [b,c,n] -> grad_points [b,c,m] (+=, atomic). */
 int gp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx, const float *weight, float *grad_points, gp_stream_t s);
 
@@ -95,10 +120,14 @@ int gp_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
  * idx_l [b,m_l] i32 (indices into the previous level's point list), new_xyz_l [b,m_l,3].  Unused levels: m = 0. */
 int gp_fps_chain(int b, int n0, int nlevels, const int *m, const float *xyz, int32_t *idx0, float *new_xyz0,
                  int32_t *idx1, float *new_xyz1, int32_t *idx2, float *new_xyz2, gp_stream_t s);
+int gp_fps_chain_arith(int arith, int b, int n0, int nlevels, const int *m, const float *xyz, int32_t *idx0, float *new_xyz0,
+                       int32_t *idx1, float *new_xyz1, int32_t *idx2, float *new_xyz2, gp_stream_t s);
 
 /* Ball query for the two scales of one MSG level in a single pass; rows with no hit are zero-filled. */
 int gp_ball_query_msg(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
                       const float *xyz, int32_t *idx0, int32_t *idx1, gp_stream_t s);
+int gp_ball_query_msg_arith(int arith, int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
+                            const float *xyz, int32_t *idx0, int32_t *idx1, gp_stream_t s);
 
 /* One scale of one set-abstraction level: gather neighbourhood -> 3-layer shared MLP (BN folded, ReLU) on
  * fp32 MFMA -> max over the neighbourhood.  Never materialises the grouped [b,C+3,np,ns] tensor.

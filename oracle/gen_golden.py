@@ -94,32 +94,53 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def gen_g1_g2(ns, arith=None):
+    """G1/G2 through the reference's own autograd Functions (pointnet2_utils.py) with the stand-in module under the arithmetic convention
+    `arith` (oracle/pn2_ops.c header; None = the oracle's default).  The default convention's file is g1_g2_ops.npz, the others
+    g1_g2_ops_arith<X>.npz - small files, one per convention, so that every arm of the switch is held to a reference-driven vector."""
+    from . import pn2_oracle
+    arith = arith or pn2_oracle.DEFAULT_ARITH
+    P = ns.pn2_utils
+    with pn2_oracle.use_arith(arith):
+        clouds = synth.golden_clouds()  # [4,1024,3]: 2 surface-like, 1 tiled-duplicate, 1 grid ties
+        xyz = torch.from_numpy(clouds)
+        g = {"clouds": clouds, "arith": np.array(arith)}
+        cur = xyz
+        for lvl, (npnt, radii, nss) in enumerate(zip([512, 256, 128], go.LIGHT_CFG["radii"], go.LIGHT_CFG["nsamples"])):
+            idx = P.furthest_point_sample(cur.contiguous(), npnt)
+            new = P.gather_operation(cur.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+            g[f"fps_idx{lvl}"] = idx.numpy().astype(np.int16)
+            for s, (r, nsmp) in enumerate(zip(radii, nss)):
+                bq = P.ball_query(r, nsmp, cur.contiguous(), new).numpy()
+                g[f"bq{lvl}_{s}_cloud0"] = bq[0].astype(np.int16)
+                g[f"bq{lvl}_{s}_sha"] = np.array([sha(bq[b].astype(np.int32)) for b in range(bq.shape[0])])
+            cur = new
+        # odd sizes: n not a power of two, tiny nsample
+        odd = torch.from_numpy(synth.golden_clouds(seed=77)[:2, :700].copy())
+        g["odd_clouds"] = odd.numpy()
+        g["odd_fps"] = P.furthest_point_sample(odd.contiguous(), 100).numpy().astype(np.int16)
+        g["odd_bq"] = P.ball_query(0.05, 5, odd.contiguous(), odd[:, :50].contiguous()).numpy().astype(np.int16)
+        # three_nn / three_interpolate (north_star lists them; the encoder does not reach them): the other two sites of the contraction
+        unknown, known = xyz[:2, :300].contiguous(), xyz[:2, 300:364].contiguous()
+        d, i3 = P.three_nn(unknown, known)
+        w = (1.0 / (d + 1e-8))
+        w = (w / w.sum(dim=2, keepdim=True)).contiguous()
+        feats = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 7, 64)).astype(np.float32))
+        g["nn_dist"], g["nn_idx"] = d.numpy(), i3.numpy().astype(np.int16)
+        g["interp_feats"], g["interp_w"] = feats.numpy(), w.numpy()
+        g["interp_out"] = P.three_interpolate(feats, i3, w).numpy()
+    name = "g1_g2_ops.npz" if arith == pn2_oracle.DEFAULT_ARITH else f"g1_g2_ops_arith{arith}.npz"
+    np.savez_compressed(os.path.join(OUT, name), **g)
+    return clouds, xyz
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_import.load()
     torch.set_grad_enabled(False)
     P = ns.pn2_utils
 
-    # ---------------- G1/G2
-    clouds = synth.golden_clouds()  # [4,1024,3]: 2 surface-like, 1 tiled-duplicate, 1 grid ties
-    xyz = torch.from_numpy(clouds)
-    g = {"clouds": clouds}
-    cur = xyz
-    for lvl, (npnt, radii, nss) in enumerate(zip([512, 256, 128], go.LIGHT_CFG["radii"], go.LIGHT_CFG["nsamples"])):
-        idx = P.furthest_point_sample(cur.contiguous(), npnt)
-        new = P.gather_operation(cur.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
-        g[f"fps_idx{lvl}"] = idx.numpy().astype(np.int16)
-        for s, (r, nsmp) in enumerate(zip(radii, nss)):
-            bq = P.ball_query(r, nsmp, cur.contiguous(), new).numpy()
-            g[f"bq{lvl}_{s}_cloud0"] = bq[0].astype(np.int16)
-            g[f"bq{lvl}_{s}_sha"] = np.array([sha(bq[b].astype(np.int32)) for b in range(bq.shape[0])])
-        cur = new
-    # odd sizes: n not a power of two, tiny nsample
-    odd = torch.from_numpy(synth.golden_clouds(seed=77)[:2, :700].copy())
-    g["odd_clouds"] = odd.numpy()
-    g["odd_fps"] = P.furthest_point_sample(odd.contiguous(), 100).numpy().astype(np.int16)
-    g["odd_bq"] = P.ball_query(0.05, 5, odd.contiguous(), odd[:, :50].contiguous()).numpy().astype(np.int16)
-    np.savez_compressed(os.path.join(OUT, "g1_g2_ops.npz"), **g)
+    clouds, xyz = gen_g1_g2(ns)
 
     # ---------------- G3 encoder
     agent, sd = make_agent(ns, "score")
@@ -584,7 +605,16 @@ def main_g16(params):
     print("wrote", f"g16_encoder_{params}.npz", feat.shape, float(feat.abs().mean()))
 
 
+def main_arith(arith):
+    """G1/G2 only, under a non-default convention (python -m oracle.gen_golden --arith A|B|C)."""
+    ns = ref_import.load()
+    torch.set_grad_enabled(False)
+    gen_g1_g2(ns, arith)
+
+
 if __name__ == "__main__":
+    if "--arith" in sys.argv:
+        sys.exit(main_arith(sys.argv[sys.argv.index("--arith") + 1]))
     if "--g16" in sys.argv:
         sys.exit(main_g16(sys.argv[sys.argv.index("--g16") + 1]))
     if "--g15" in sys.argv:

@@ -10,22 +10,48 @@
  * "PARITY UNPINNED": it follows the .cu text line by line, but no golden
  * vector produced by the CUDA code exists to check it against.
  *
- * Arithmetic pin: squared distances are evaluated as the
- * FMA chain nvcc emits for `dx*dx + dy*dy + dz*dz` under its default
- * --fmad=true:  fmaf(dz,dz, fmaf(dy,dy, dx*dx)).  Build with
- * -ffp-contract=off so the compiler adds no contraction of its own.
+ * Arithmetic convention (`arith`, first argument of every function that evaluates a sum of three
+ * products).  The .cu text says `dx*dx + dy*dy + dz*dz` (sampling_gpu.cu:133, ball_query_gpu.cu:33,
+ * interpolate_gpu.cu:36) and `w0*p0 + w1*p1 + w2*p2` (interpolate_gpu.cu:95); the reference builds with
+ * plain `nvcc -O2` (setup.py:19-20), i.e. --fmad=true, so nvcc contracts - HOW is a property of its
+ * compiler, which this image does not have.  Three conventions, all restated here (DESIGN.md §5 has the
+ * evidence for the default):
+ *   GPO_ARITH_A = 0   fma(c,c, fma(b,b, a*a))    first product rounded, then fused left to right
+ *   GPO_ARITH_B = 1   fma(c,c, fma(a,a, b*b))    what LLVM's DAG combiner and GCC emit for this text
+ *                                                (the first fadd fuses its LEFT operand's multiply): DEFAULT
+ *   GPO_ARITH_C = 2   (a*a + b*b) + c*c          no contraction (nvcc --fmad=false)
+ * Build with -ffp-contract=off so the compiler adds no contraction of its own.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-static inline float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+enum { GPO_ARITH_A = 0, GPO_ARITH_B = 1, GPO_ARITH_C = 2 };
+
+/* a0*b0 + a1*b1 + a2*b2 under the three conventions */
+static inline float dot3(int arith, float a0, float b0, float a1, float b1, float a2, float b2) {
+    if (arith == GPO_ARITH_A) {
+        float m = a0 * b0;
+        return fmaf(a2, b2, fmaf(a1, b1, m));
+    }
+    if (arith == GPO_ARITH_B) {
+        float m = a1 * b1;
+        return fmaf(a2, b2, fmaf(a0, b0, m));
+    }
+    float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+    float s = p0 + p1;
+    return s + p2;
+}
+
+static inline float sqdist(int arith, float ax, float ay, float az, float bx, float by, float bz) {
     /* operand order as written in the .cu: (a - b) */
     float dx = ax - bx, dy = ay - by, dz = az - bz;
-    float m = dx * dx;
-    return fmaf(dz, dz, fmaf(dy, dy, m));
+    return dot3(arith, dx, dx, dy, dy, dz, dz);
 }
+int gpo_arith_valid(int arith) { return arith >= GPO_ARITH_A && arith <= GPO_ARITH_C; }
+/* one squared distance (tests: the three conventions differ on crafted inputs) */
+float gpo_sqdist(int arith, const float *a, const float *b) { return sqdist(arith, a[0], a[1], a[2], b[0], b[1], b[2]); }
 
 /* cuda_utils.h:10-14  opt_n_threads */
 static int opt_n_threads(int work_size) {
@@ -44,7 +70,8 @@ int gpo_opt_n_threads(int n) { return opt_n_threads(n); }
  * tree produces - not an independently derived closed form.
  * dataset (B,N,3)  temp (B,N) in/out  idxs (B,M) out.
  */
-int gpo_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int32_t *idxs) {
+int gpo_furthest_point_sampling(int arith, int b, int n, int m, const float *dataset, float *temp, int32_t *idxs) {
+    if (!gpo_arith_valid(arith)) return -1;
     if (m <= 0) return 0;
     const int S = opt_n_threads(n);
 #pragma omp parallel for schedule(dynamic)
@@ -63,7 +90,7 @@ int gpo_furthest_point_sampling(int b, int n, int m, const float *dataset, float
                 float best = -1.0f;
                 for (int k = tid; k < n; k += S) {
                     float x2 = ds[k * 3 + 0], y2 = ds[k * 3 + 1], z2 = ds[k * 3 + 2];
-                    float d = sqdist(x2, y2, z2, x1, y1, z1);
+                    float d = sqdist(arith, x2, y2, z2, x1, y1, z1);
                     float d2 = fminf(d, tp[k]);
                     tp[k] = d2;
                     besti = d2 > best ? k : besti;
@@ -100,7 +127,8 @@ int gpo_gather_points(int b, int c, int n, int m, const float *points, const int
 
 /* ball_query_gpu.cu:9-45: new_xyz (B,M,3), xyz (B,N,3) -> idx (B,M,nsample); idx is NOT cleared here
  * (the Python caller pre-zeroes it, pointnet2_utils.py:219). */
-int gpo_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx) {
+int gpo_ball_query(int arith, int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx) {
+    if (!gpo_arith_valid(arith)) return -1;
     float radius2 = radius * radius;
 #pragma omp parallel for schedule(dynamic)
     for (int bi = 0; bi < b; ++bi) {
@@ -111,7 +139,7 @@ int gpo_ball_query(int b, int n, int m, float radius, int nsample, const float *
             float nx = c[0], ny = c[1], nz = c[2];
             int cnt = 0;
             for (int k = 0; k < n; ++k) {
-                float d2 = sqdist(nx, ny, nz, X[k * 3 + 0], X[k * 3 + 1], X[k * 3 + 2]);
+                float d2 = sqdist(arith, nx, ny, nz, X[k * 3 + 0], X[k * 3 + 1], X[k * 3 + 2]);
                 if (d2 < radius2) {
                     if (cnt == 0)
                         for (int l = 0; l < nsample; ++l) o[l] = k;
@@ -140,7 +168,7 @@ int gpo_group_points(int b, int c, int n, int npoints, int nsample, const float 
 
 /* interpolate_gpu.cu:9-52 three_nn_kernel_fast: unknown (B,N,3), known (B,M,3) -> dist2 (B,N,3), idx (B,N,3).
  * best1..3 are doubles initialised to 1e40, d is float compared after promotion. */
-int gpo_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx) {
+int gpo_three_nn(int arith, int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx) {
     for (int bi = 0; bi < b; ++bi)
         for (int p = 0; p < n; ++p) {
             const float *u = unknown + ((size_t)bi * n + p) * 3;
@@ -148,7 +176,7 @@ int gpo_three_nn(int b, int n, int m, const float *unknown, const float *known, 
             double best1 = 1e40, best2 = 1e40, best3 = 1e40;
             int besti1 = 0, besti2 = 0, besti3 = 0;
             for (int k = 0; k < m; ++k) {
-                float d = sqdist(u[0], u[1], u[2], K[k * 3 + 0], K[k * 3 + 1], K[k * 3 + 2]);
+                float d = sqdist(arith, u[0], u[1], u[2], K[k * 3 + 0], K[k * 3 + 1], K[k * 3 + 2]);
                 if (d < best1) {
                     best3 = best2; besti3 = besti2;
                     best2 = best1; besti2 = besti1;
@@ -169,16 +197,15 @@ int gpo_three_nn(int b, int n, int m, const float *unknown, const float *known, 
 }
 
 /* interpolate_gpu.cu:77-96 three_interpolate_kernel_fast: points (B,C,M), idx/weight (B,N,3) -> out (B,C,N).
- * `w0*p0 + w1*p1 + w2*p2` contracts under nvcc to fma(w2,p2, fma(w1,p1, w0*p0)). */
-int gpo_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out) {
+ * `w0*p0 + w1*p1 + w2*p2`: the same three conventions as the squared distance (dot3). */
+int gpo_three_interpolate(int arith, int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out) {
     for (int bi = 0; bi < b; ++bi)
         for (int ci = 0; ci < c; ++ci) {
             const float *src = points + ((size_t)bi * c + ci) * m;
             for (int p = 0; p < n; ++p) {
                 const float *w = weight + ((size_t)bi * n + p) * 3;
                 const int32_t *id = idx + ((size_t)bi * n + p) * 3;
-                float t = w[0] * src[id[0]];
-                out[((size_t)bi * c + ci) * n + p] = fmaf(w[2], src[id[2]], fmaf(w[1], src[id[1]], t));
+                out[((size_t)bi * c + ci) * n + p] = dot3(arith, w[0], src[id[0]], w[1], src[id[1]], w[2], src[id[2]]);
             }
         }
     return 1;

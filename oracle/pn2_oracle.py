@@ -6,10 +6,40 @@ with the 9 pybind names of pointnet2_api.cpp:10-24 operating in place on CPU tor
 the import shim (oracle/ref_import.py) installs as `pointnet2_cuda` so that the reference's own
 Python can run in the build container.
 """
+import contextlib
 import ctypes
 import os
 import subprocess
 import numpy as np
+
+# How `a*a + b*b + c*c` (sampling_gpu.cu:133, ball_query_gpu.cu:33, interpolate_gpu.cu:36,95) is contracted - see oracle/pn2_ops.c.
+#   "A" fma(c,c, fma(b,b, a*a))   "B" fma(c,c, fma(a,a, b*b)) (what LLVM and GCC emit for the text; default)   "C" no contraction
+ARITH_CODES = {"A": 0, "B": 1, "C": 2}
+DEFAULT_ARITH = "B"   # must equal genpose_amd.config.DEFAULT_DIST_ARITH (tests/test_abi_and_host.py asserts it)
+_current = [DEFAULT_ARITH]
+
+
+def current_arith():
+    return _current[-1]
+
+
+@contextlib.contextmanager
+def use_arith(arith):
+    """Every oracle call inside the block (also through genpose_oracle / the imported reference's stand-in module) uses `arith`
+    unless it names its own."""
+    code(arith)
+    _current.append(arith)
+    try:
+        yield
+    finally:
+        _current.pop()
+
+
+def code(arith=None):
+    a = _current[-1] if arith is None else arith
+    if a not in ARITH_CODES:
+        raise ValueError(f"arith must be one of {sorted(ARITH_CODES)}, got {a!r}")
+    return ARITH_CODES[a]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "build", "libpn2_oracle.so")
@@ -47,7 +77,16 @@ def opt_n_threads(n):
     return lib().gpo_opt_n_threads(int(n))
 
 
-def furthest_point_sampling(xyz, m, temp=None):
+def sqdist(a, b, arith=None):
+    """One squared distance |a - b|^2 of two float32 3-vectors under `arith`."""
+    a, pa = _f(a)
+    b, pb = _f(b)
+    fn = lib().gpo_sqdist
+    fn.restype = ctypes.c_float
+    return np.float32(fn(code(arith), pa, pb))
+
+
+def furthest_point_sampling(xyz, m, temp=None, arith=None):
     """xyz (B,N,3) f32 -> idx (B,m) i32; temp (B,N) starts at 1e10 (pointnet2_utils.py:27)."""
     xyz, px = _f(xyz)
     B, N, _ = xyz.shape
@@ -55,7 +94,7 @@ def furthest_point_sampling(xyz, m, temp=None):
         temp = np.full((B, N), 1e10, dtype=np.float32)
     temp, pt = _f(temp)
     idx = np.zeros((B, m), dtype=np.int32)
-    lib().gpo_furthest_point_sampling(B, N, int(m), px, pt, idx.ctypes.data_as(ctypes.c_void_p))
+    lib().gpo_furthest_point_sampling(code(arith), B, N, int(m), px, pt, idx.ctypes.data_as(ctypes.c_void_p))
     return idx, temp
 
 
@@ -70,14 +109,14 @@ def gather_points(points, idx):
     return out
 
 
-def ball_query(radius, nsample, xyz, new_xyz):
+def ball_query(radius, nsample, xyz, new_xyz, arith=None):
     """xyz (B,N,3), new_xyz (B,M,3) -> idx (B,M,nsample) i32 (pre-zeroed as pointnet2_utils.py:219)."""
     xyz, px = _f(xyz)
     new_xyz, pn = _f(new_xyz)
     B, N, _ = xyz.shape
     M = new_xyz.shape[1]
     idx = np.zeros((B, M, nsample), dtype=np.int32)
-    lib().gpo_ball_query(B, N, M, ctypes.c_float(radius), int(nsample), pn, px, idx.ctypes.data_as(ctypes.c_void_p))
+    lib().gpo_ball_query(code(arith), B, N, M, ctypes.c_float(radius), int(nsample), pn, px, idx.ctypes.data_as(ctypes.c_void_p))
     return idx
 
 
@@ -92,25 +131,25 @@ def group_points(points, idx):
     return out
 
 
-def three_nn(unknown, known):
+def three_nn(unknown, known, arith=None):
     unknown, pu = _f(unknown)
     known, pk = _f(known)
     B, N, _ = unknown.shape
     M = known.shape[1]
     d = np.empty((B, N, 3), dtype=np.float32)
     i = np.empty((B, N, 3), dtype=np.int32)
-    lib().gpo_three_nn(B, N, M, pu, pk, d.ctypes.data_as(ctypes.c_void_p), i.ctypes.data_as(ctypes.c_void_p))
+    lib().gpo_three_nn(code(arith), B, N, M, pu, pk, d.ctypes.data_as(ctypes.c_void_p), i.ctypes.data_as(ctypes.c_void_p))
     return d, i
 
 
-def three_interpolate(points, idx, weight):
+def three_interpolate(points, idx, weight, arith=None):
     points, pp = _f(points)
     idx, pi = _i(idx)
     weight, pw = _f(weight)
     B, C, M = points.shape
     N = idx.shape[1]
     out = np.empty((B, C, N), dtype=np.float32)
-    lib().gpo_three_interpolate(B, C, M, N, pp, pi, pw, out.ctypes.data_as(ctypes.c_void_p))
+    lib().gpo_three_interpolate(code(arith), B, C, M, N, pp, pi, pw, out.ctypes.data_as(ctypes.c_void_p))
     return out
 
 
@@ -143,7 +182,8 @@ def three_interpolate_grad(grad_out, idx, weight, m):
 
 
 class _Pointnet2CudaCPU:
-    """CPU object with the pybind surface of pointnet2_api.cpp:10-24 (in-place on CPU torch tensors)."""
+    """CPU object with the pybind surface of pointnet2_api.cpp:10-24 (in-place on CPU torch tensors).  The arithmetic convention
+    is the oracle's current one (use_arith) at the time of each call."""
 
     @staticmethod
     def _p(t):
@@ -151,7 +191,7 @@ class _Pointnet2CudaCPU:
         return ctypes.c_void_p(t.data_ptr())
 
     def furthest_point_sampling_wrapper(self, b, n, m, points, temp, idx):
-        lib().gpo_furthest_point_sampling(b, n, m, self._p(points), self._p(temp), self._p(idx))
+        lib().gpo_furthest_point_sampling(code(), b, n, m, self._p(points), self._p(temp), self._p(idx))
         return 1
 
     def gather_points_wrapper(self, b, c, n, npoints, points, idx, out):
@@ -159,7 +199,7 @@ class _Pointnet2CudaCPU:
         return 1
 
     def ball_query_wrapper(self, b, n, m, radius, nsample, new_xyz, xyz, idx):
-        lib().gpo_ball_query(b, n, m, ctypes.c_float(radius), nsample, self._p(new_xyz), self._p(xyz), self._p(idx))
+        lib().gpo_ball_query(code(), b, n, m, ctypes.c_float(radius), nsample, self._p(new_xyz), self._p(xyz), self._p(idx))
         return 1
 
     def group_points_wrapper(self, b, c, n, npoints, nsample, points, idx, out):
@@ -167,11 +207,11 @@ class _Pointnet2CudaCPU:
         return 1
 
     def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
-        lib().gpo_three_nn(b, n, m, self._p(unknown), self._p(known), self._p(dist2), self._p(idx))
+        lib().gpo_three_nn(code(), b, n, m, self._p(unknown), self._p(known), self._p(dist2), self._p(idx))
         return 1
 
     def three_interpolate_wrapper(self, b, c, m, n, points, idx, weight, out):
-        lib().gpo_three_interpolate(b, c, m, n, self._p(points), self._p(idx), self._p(weight), self._p(out))
+        lib().gpo_three_interpolate(code(), b, c, m, n, self._p(points), self._p(idx), self._p(weight), self._p(out))
 
     def group_points_grad_wrapper(self, b, c, n, npoints, nsample, grad_out, idx, grad_points):
         lib().gpo_group_points_grad(b, c, n, npoints, nsample, self._p(grad_out), self._p(idx), self._p(grad_points))

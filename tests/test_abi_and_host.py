@@ -33,6 +33,34 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().gp_version() == 1
 
 
+def test_arithmetic_convention_defaults_agree():
+    """ONE default for the contraction convention of the three-product sums (include/genpose_hip.h GP_ARITH_*): the header's macro, what
+    the built library reports, the Python config the encoder / operator module read, and the oracle's - a flip has to move all four."""
+    from genpose_amd import _lib, config
+    from oracle import pn2_oracle as ops
+    import genpose_amd.pointnet2_cuda as m
+    hdr = open(os.path.join(ROOT, "include", "genpose_hip.h")).read()
+    codes = {k: int(v) for k, v in re.findall(r"#define GP_ARITH_([ABC]) (\d)", hdr)}
+    assert codes == config.DIST_ARITH_CODES == ops.ARITH_CODES
+    default_macro = re.search(r"#define GP_ARITH_DEFAULT GP_ARITH_([ABC])", hdr).group(1)
+    assert default_macro == config.DEFAULT_DIST_ARITH == ops.DEFAULT_ARITH == m.ARITH == config.get_config().dist_arith
+    assert _lib.lib().gp_arith_default() == codes[default_macro]
+    with pytest.raises(ValueError):
+        config.dist_arith_code("D")
+    with pytest.raises(ValueError):
+        m.set_arith("fast")
+    from genpose_amd.encoder import Pointnet2EncoderHIP
+    sd = go.make_state_dict(0, "score")
+    encs = {a: Pointnet2EncoderHIP(sd, "cpu", arith=a) for a in "ABC"}
+    assert [encs[a].arith for a in "ABC"] == [0, 1, 2]
+    # a grouping computed under one convention is not handed to an encoder that runs another
+    assert len({encs[a].grouping_key() for a in "ABC"}) == 3
+    assert Pointnet2EncoderHIP(sd, "cpu").grouping_key() == encs[config.DEFAULT_DIST_ARITH].grouping_key()
+    # bad convention at the C boundary: GP_EINVAL, no launch
+    assert _lib.lib().gp_furthest_point_sampling_arith(7, 1, 8, 2, None, None, None, None) == -1
+    assert _lib.lib().gp_ball_query_msg_arith(-1, 1, 8, 2, 0.1, 4, 0.2, 4, None, None, None, None, None) == -1
+
+
 def test_pointnet2_cuda_surface_matches_reference_names():
     """The nine pybind names of pointnet2_api.cpp:10-24."""
     import genpose_amd.pointnet2_cuda as m

@@ -42,6 +42,43 @@ def test_encoder_vs_oracle_batches(enc, sd):
         np.testing.assert_allclose(got, ref, rtol=ENC_RTOL, atol=ENC_ATOL)
 
 
+@pytest.mark.parametrize("arith", ["A", "B", "C"])
+def test_encoder_under_every_distance_convention(sd, golden, arith):
+    """The contraction convention of the grouping operators' squared distances (include/genpose_hip.h GP_ARITH_*) as an encoder / agent
+    field: under each of the three the centres and neighbourhoods of every level equal the oracle's under the SAME convention bit for
+    bit - on clouds where the conventions disagree (golden clouds: grid ties, tiled duplicates; synthetic clouds 23 and 74 of the
+    2048-cloud sensitivity run, profiles/r5_arith_sensitivity.txt) - and the features follow to the fp32 tolerance."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.encoder import Pointnet2EncoderHIP
+    from genpose_amd.posenet_agent import PoseNet
+    from oracle import pn2_oracle as ops
+    all_synth = synth.make_batch(75)
+    pts = np.concatenate([golden("g3_encoder.npz")["clouds"], all_synth[[23, 74, 5]]])
+    enc_a = Pointnet2EncoderHIP(sd, "cuda", arith=arith)
+    feat, ws = enc_a.forward(torch.from_numpy(pts).cuda(), return_intermediates=True)
+    with ops.use_arith(arith):
+        ref, inter = go.encoder_forward(sd, torch.from_numpy(pts), return_intermediates=True)
+    for lvl in range(3):
+        assert np.array_equal(ws["fps_idx"][lvl].cpu().numpy(), inter[lvl]["fps_idx"]), f"{arith}: FPS level {lvl}"
+        assert np.array_equal(ws["new_xyz"][lvl].cpu().numpy(), inter[lvl]["new_xyz"])
+        for s in range(2):
+            assert np.array_equal(ws["bq"][lvl][s].cpu().numpy(), inter[lvl][f"bq_idx{s}"]), f"{arith}: ball query level {lvl} scale {s}"
+    np.testing.assert_allclose(feat.cpu().numpy(), ref.numpy(), rtol=ENC_RTOL, atol=ENC_ATOL)
+    # the conventions really select differently on these clouds (level-0 picks of the two synthetic clouds)
+    if arith != ops.DEFAULT_ARITH:
+        dflt = ops.furthest_point_sampling(pts, 512)[0]
+        assert not np.array_equal(dflt, inter[0]["fps_idx"])
+    # and through the agent: cfg.dist_arith
+    agent = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"], dist_arith=arith))
+    agent.load_state_dict(sd)
+    assert agent.net.pts_encoder.arith == ops.ARITH_CODES[arith]
+    data = {"pts": torch.from_numpy(pts).cuda()}
+    got = agent.net.extract_pts_feature(data) if hasattr(agent.net, "extract_pts_feature") else None
+    if got is not None:
+        assert torch.equal(got, feat)
+
+
 def test_encoder_is_deterministic_and_batch_independent(enc):
     from genpose_amd import synth
     pts = torch.from_numpy(synth.make_batch(8, 7)).cuda()

@@ -21,6 +21,23 @@ def pn2():
     return m
 
 
+@pytest.fixture(params=["A", "B", "C"])
+def arith(request, pn2):
+    """Every contraction convention of the three-product sums (include/genpose_hip.h GP_ARITH_*): the operator module and the oracle
+    are switched together, so each test below holds the HIP kernels to the oracle bit for bit under all three."""
+    from genpose_amd.config import DEFAULT_DIST_ARITH
+    pn2.set_arith(request.param)
+    try:
+        with ops.use_arith(request.param):
+            yield request.param
+    finally:
+        pn2.set_arith(DEFAULT_DIST_ARITH)
+
+
+def golden_name(arith):
+    return "g1_g2_ops.npz" if arith == ops.DEFAULT_ARITH else f"g1_g2_ops_arith{arith}.npz"
+
+
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -42,8 +59,9 @@ def hip_bq(pn2, r, ns, xyz, new_xyz):
     return idx.cpu().numpy()
 
 
-def test_fps_bq_golden(pn2, golden):
-    g = golden("g1_g2_ops.npz")
+def test_fps_bq_golden(pn2, golden, arith):
+    g = golden(golden_name(arith))
+    assert str(g["arith"]) == arith
     cur = g["clouds"]
     radii = [[0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]
     for lvl, npnt in enumerate([512, 256, 128]):
@@ -58,11 +76,38 @@ def test_fps_bq_golden(pn2, golden):
     odd = g["odd_clouds"]
     assert np.array_equal(hip_fps(pn2, odd, 100)[0], g["odd_fps"])
     assert np.array_equal(hip_bq(pn2, 0.05, 5, odd, np.ascontiguousarray(odd[:, :50])), g["odd_bq"])
+    # the other two sites of the contraction (interpolate_gpu.cu:36,95), captured through the reference's three_nn / three_interpolate
+    unk, kn = np.ascontiguousarray(g["clouds"][:2, :300]), np.ascontiguousarray(g["clouds"][:2, 300:364])
+    d2 = torch.empty(2, 300, 3, device="cuda")
+    i3 = torch.empty(2, 300, 3, dtype=torch.int32, device="cuda")
+    pn2.three_nn_wrapper(2, 300, 64, dev(unk), dev(kn), d2, i3)
+    assert np.array_equal(i3.cpu().numpy(), g["nn_idx"].astype(np.int32))
+    assert np.array_equal(torch.sqrt(d2.cpu()).numpy(), g["nn_dist"])  # pointnet2_utils.py:99 returns torch.sqrt(dist2) (host tensor there)
+    out = torch.empty(2, 7, 300, device="cuda")
+    pn2.three_interpolate_wrapper(2, 7, 64, 300, dev(g["interp_feats"]), i3, dev(g["interp_w"]), out)
+    assert np.array_equal(out.cpu().numpy(), g["interp_out"])
+
+
+def test_conventions_pick_different_centres(pn2):
+    """The switch is not a no-op: on the golden clouds (exact grid ties, tiled duplicates) the three conventions select different points,
+    and the HIP kernels follow the oracle into each of them (test_fps_bq_golden); here: the default is B, and A / C differ from it."""
+    from genpose_amd.config import DEFAULT_DIST_ARITH
+    assert pn2.ARITH == DEFAULT_DIST_ARITH == ops.DEFAULT_ARITH == "B"
+    from tests.conftest import load_golden
+    clouds = load_golden("g1_g2_ops.npz")["clouds"]
+    got = {}
+    for a in "ABC":
+        pn2.set_arith(a)
+        try:
+            got[a] = hip_fps(pn2, clouds, 512)[0]
+        finally:
+            pn2.set_arith(DEFAULT_DIST_ARITH)
+    assert not np.array_equal(got["A"], got["B"]) and not np.array_equal(got["B"], got["C"]) and not np.array_equal(got["A"], got["C"])
 
 
 @pytest.mark.parametrize("n,m", [(1024, 512), (512, 256), (256, 128), (700, 100), (64, 64), (65, 7), (3, 2), (1, 1), (1500, 300),
                                  (4096, 64), (5000, 40)])
-def test_fps_vs_oracle(pn2, n, m):
+def test_fps_vs_oracle(pn2, arith, n, m):
     rng = np.random.default_rng(n * 7 + m)
     xyz = (rng.normal(size=(3, n, 3)) * 0.1).astype(np.float32)
     xyz[1] = np.round(xyz[1] * 50) / 50  # many exact ties
@@ -74,7 +119,7 @@ def test_fps_vs_oracle(pn2, n, m):
     assert np.array_equal(got_t, ref_t)  # running min distances persist bit-exactly
 
 
-def test_fps_respects_temp_and_ties(pn2):
+def test_fps_respects_temp_and_ties(pn2, arith):
     p = np.array([[[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0.5, 0, 0]]], dtype=np.float32)
     assert hip_fps(pn2, p, 3)[0].tolist() == [[0, 2, 1]]
     q = np.zeros((1, 8, 3), dtype=np.float32)
@@ -90,7 +135,7 @@ def test_fps_respects_temp_and_ties(pn2):
 
 @pytest.mark.parametrize("n,m,r,ns", [(1024, 512, 0.02, 16), (1024, 512, 0.04, 32), (512, 256, 0.08, 32), (256, 128, 0.16, 32),
                                       (700, 50, 0.05, 5), (100, 100, 10.0, 64), (70, 3, 1e-6, 8), (6000, 33, 0.1, 20)])
-def test_ball_query_vs_oracle(pn2, n, m, r, ns):
+def test_ball_query_vs_oracle(pn2, arith, n, m, r, ns):
     rng = np.random.default_rng(n + m)
     xyz = (rng.normal(size=(2, n, 3)) * 0.08).astype(np.float32)
     new = np.ascontiguousarray(xyz[:, rng.permutation(n)[:m]])
@@ -108,19 +153,28 @@ def test_ball_query_radius_tie_is_strict(pn2):
     assert hip_bq(pn2, 0.5, 4, xyz, new).tolist() == ops.ball_query(0.5, 4, xyz, new).tolist() == [[[0, 2, 0, 0]]]
 
 
-def test_msg_ball_query_and_chain(golden):
-    """Fused entry points used by the encoder: gp_fps_chain / gp_ball_query_msg."""
+def test_msg_ball_query_and_chain(golden, arith):
+    """Fused entry points used by the encoder: gp_fps_chain / gp_ball_query_msg (+ their `_arith` twins: every convention)."""
     import ctypes
     from genpose_amd import _lib
     from genpose_amd._lib import ptr, stream_ptr
-    g = golden("g1_g2_ops.npz")
+    from genpose_amd.config import dist_arith_code
+    g = golden(golden_name(arith))
+    ac = dist_arith_code(arith)
     xyz = dev(g["clouds"])
     B = xyz.shape[0]
     ms = [512, 256, 128]
     idx = [torch.empty(B, m, dtype=torch.int32, device="cuda") for m in ms]
     nx = [torch.empty(B, m, 3, device="cuda") for m in ms]
-    _lib.call("gp_fps_chain", B, 1024, 3, (ctypes.c_int * 3)(*ms), ptr(xyz), ptr(idx[0]), ptr(nx[0]), ptr(idx[1]), ptr(nx[1]),
+    _lib.call("gp_fps_chain_arith", ac, B, 1024, 3, (ctypes.c_int * 3)(*ms), ptr(xyz), ptr(idx[0]), ptr(nx[0]), ptr(idx[1]), ptr(nx[1]),
               ptr(idx[2]), ptr(nx[2]), stream_ptr())
+    if arith == ops.DEFAULT_ARITH:  # the un-suffixed entry points ARE the default convention
+        assert _lib.lib().gp_arith_default() == ac
+        idx_d = [torch.empty_like(t) for t in idx]
+        nx_d = [torch.empty_like(t) for t in nx]
+        _lib.call("gp_fps_chain", B, 1024, 3, (ctypes.c_int * 3)(*ms), ptr(xyz), ptr(idx_d[0]), ptr(nx_d[0]), ptr(idx_d[1]), ptr(nx_d[1]),
+                  ptr(idx_d[2]), ptr(nx_d[2]), stream_ptr())
+        assert all(torch.equal(a, b) for a, b in zip(idx + nx, idx_d + nx_d))
     cur = g["clouds"]
     for l in range(3):
         assert np.array_equal(idx[l].cpu().numpy(), g[f"fps_idx{l}"].astype(np.int32))
@@ -129,7 +183,7 @@ def test_msg_ball_query_and_chain(golden):
         i0 = torch.full((B, ms[l], 16), -7, dtype=torch.int32, device="cuda")
         i1 = torch.full((B, ms[l], 32), -7, dtype=torch.int32, device="cuda")
         r = [[0.02, 0.04], [0.04, 0.08], [0.08, 0.16]][l]
-        _lib.call("gp_ball_query_msg", B, cur.shape[1], ms[l], r[0], 16, r[1], 32, ptr(nx[l]), ptr(dev(cur)), ptr(i0), ptr(i1), stream_ptr())
+        _lib.call("gp_ball_query_msg_arith", ac, B, cur.shape[1], ms[l], r[0], 16, r[1], 32, ptr(nx[l]), ptr(dev(cur)), ptr(i0), ptr(i1), stream_ptr())
         assert np.array_equal(i0.cpu().numpy(), ops.ball_query(r[0], 16, cur, new))
         assert np.array_equal(i1.cpu().numpy(), ops.ball_query(r[1], 32, cur, new))
         cur = np.ascontiguousarray(new)
@@ -157,7 +211,7 @@ def test_gather_group(pn2):
     np.testing.assert_allclose(gp.cpu().numpy(), ops.gather_points_grad(go2, idx, 200), rtol=1e-5, atol=1e-5)
 
 
-def test_three_nn_interpolate(pn2):
+def test_three_nn_interpolate(pn2, arith):
     rng = np.random.default_rng(9)
     for (n, m) in [(300, 64), (50, 3), (1000, 3000)]:
         unk = rng.normal(size=(2, n, 3)).astype(np.float32)

@@ -24,8 +24,38 @@ def sd_energy():
     return go.make_state_dict(0, "energy")
 
 
-def test_g1_g2_ops(golden):
-    g = golden("g1_g2_ops.npz")
+@pytest.mark.parametrize("arith", ["A", "B", "C"])
+def test_g1_g2_ops(golden, arith):
+    """One fixture per contraction convention (oracle/pn2_ops.c header), each captured through the imported reference's own
+    pointnet2_utils Functions with the stand-in module under that convention."""
+    g = golden("g1_g2_ops.npz" if arith == ops.DEFAULT_ARITH else f"g1_g2_ops_arith{arith}.npz")
+    assert str(g["arith"]) == arith
+    with ops.use_arith(arith):
+        _check_g1_g2(g)
+
+
+def test_conventions_differ_and_default_is_B(golden):
+    """The three fixtures are not copies of one another, and the un-suffixed one is convention B."""
+    f = {a: golden("g1_g2_ops.npz" if a == ops.DEFAULT_ARITH else f"g1_g2_ops_arith{a}.npz") for a in "ABC"}
+    assert ops.DEFAULT_ARITH == "B" and str(f["B"]["arith"]) == "B"
+    for x, y in (("A", "B"), ("B", "C"), ("A", "C")):
+        assert not np.array_equal(f[x]["fps_idx0"], f[y]["fps_idx0"])
+        assert not np.array_equal(f[x]["interp_out"], f[y]["interp_out"])
+    # a single squared distance on which the three conventions round differently
+    a, b = np.array([0.1, 0.2, 0.3], np.float32), np.array([0.7, -0.4, 0.05], np.float32)
+    rng = np.random.default_rng(0)
+    seen = set()
+    for _ in range(200):
+        a, b = rng.normal(size=3).astype(np.float32), rng.normal(size=3).astype(np.float32)
+        seen.add(len({float(ops.sqdist(a, b, arith=k)).hex() for k in "ABC"}))
+    assert 3 in seen  # some pair separates all three
+    d = [np.float64(x) for x in (a - b)]
+    exact = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+    for k in "ABC":
+        assert abs(float(ops.sqdist(a, b, arith=k)) - exact) <= 2 * np.spacing(np.float32(exact))
+
+
+def _check_g1_g2(g):
     cur = g["clouds"]
     for lvl, npnt in enumerate([512, 256, 128]):
         idx, _ = ops.furthest_point_sampling(cur, npnt)
@@ -41,6 +71,11 @@ def test_g1_g2_ops(golden):
     odd = g["odd_clouds"]
     assert np.array_equal(ops.furthest_point_sampling(odd, 100)[0], g["odd_fps"])
     assert np.array_equal(ops.ball_query(0.05, 5, odd, np.ascontiguousarray(odd[:, :50])), g["odd_bq"])
+    unk, kn = np.ascontiguousarray(g["clouds"][:2, :300]), np.ascontiguousarray(g["clouds"][:2, 300:364])
+    d2, i3 = ops.three_nn(unk, kn)
+    assert np.array_equal(i3, g["nn_idx"].astype(np.int32))
+    assert np.array_equal(torch.sqrt(torch.from_numpy(d2)).numpy(), g["nn_dist"])  # pointnet2_utils.py:99 returns torch.sqrt(dist2)
+    assert np.array_equal(ops.three_interpolate(g["interp_feats"], i3, g["interp_w"]), g["interp_out"])
 
 
 def test_fps_tie_rule_is_bit_reversal():
