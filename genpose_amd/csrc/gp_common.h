@@ -7,13 +7,19 @@
 
 static inline int gp_launch_status() { return hipGetLastError() == hipSuccess ? GP_OK : GP_ELAUNCH; }
 
-// Compute units of the current device (MI355X: 256 in 8 XCDs), queried once: persistent grids are sized from it.
+// Compute units of the CURRENT device (MI355X: 256 in 8 XCDs), queried once per device ordinal: persistent grids are sized from it.
+// (Per device, not per process: a process may hold partitioned and unpartitioned devices side by side.  The table is filled with plain
+// stores of an idempotent value - two threads racing on one slot write the same number.)
 static inline int gp_num_cus() {
-    static int n = 0;
+    constexpr int MAXDEV = 64;
+    static int cus[MAXDEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) dev = 0;
+    int n = cus[dev];
     if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n = v;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = n = v;
     }
     return n;
 }

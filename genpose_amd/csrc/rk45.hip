@@ -949,8 +949,10 @@ static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *pro
  * ngroups independent batches (nclouds_per_group clouds each, rows / clouds / state laid out group-major) advance with their OWN
  * step controllers - error norm, accept / reject, step size per group, exactly as separate solve_ivp calls - and share every
  * launch; a finished group's workgroups exit at once.  state: ngroups * gp_rk45_state_bytes(); tvec [ngroups][8][768];
- * partials [3][nblocks], nblocks = ngroups * ceil(rows_per_group / tile), tile from gp_pc_tile_rows (an upper bound: large score-model
- * launches run the stage kernels in the 128-row chain form, gp_rk45_plan_rows).  plan: 0 = pick, 16 / 32 / 128 = force. */
+ * partials [3][nblocks], nblocks = ngroups * ceil(rows_per_group / rows per workgroup).  plan (include/genpose_hip.h): rows per workgroup
+ * of the stage kernels - 16 / 32 / 64 = tile form (models 1 and 2: 16 only), 128 = the chain form of the trunk (EVERY model since round 4:
+ * with plan = 0, gp_rk45_plan_rows() also picks it for models 1 and 2 from ~24 600 rows, trunk_chain_vjp.h), 0 = pick.  A partials
+ * buffer sized for 16-row tiles (gp_pc_tile_rows) is an upper bound for every model and every plan. */
 int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,

@@ -19,6 +19,7 @@ import torch
 from . import _lib
 from ._lib import ptr, stream_ptr
 from .config import dist_arith_code
+from .lru import ShapeCache
 from .weights import EncoderWeights
 
 
@@ -34,7 +35,33 @@ class Pointnet2EncoderHIP:
         self.w = EncoderWeights(state_dict, self.device, params, prefix)
         self.cfg = self.w.cfg
         self.out_dim = self.w.out_dim
-        self._ws = {}
+        # workspaces (~1.5 MB per cloud) per (batch, points, slot): least recently used first, except those a captured graph writes
+        # into (`_pins`: taken by whoever captures, given back when that graph is dropped)
+        self._ws = ShapeCache(self.MAX_WORKSPACES, can_evict=lambda ws: ws.get("_pins", 0) == 0)
+        self._pass_graphs = ShapeCache(self.MAX_PASS_GRAPHS, on_evict=lambda k, ent: self._unpin(ent))
+        self._seen_once = ShapeCache(4 * self.MAX_PASS_GRAPHS)
+
+    MAX_WORKSPACES = 12
+
+    def _unpin(self, ent):
+        for ws in ent.get("pinned", ()):
+            ws["_pins"] = ws.get("_pins", 1) - 1
+
+    def pin_workspaces(self, B, N, slot=0):
+        """For whoever CAPTURES launches of this encoder in a hipGraph: the workspace of that geometry stays out of the eviction order
+        while the graph lives (its buffers were allocated outside the capture; nothing but this cache holds them).  Returns the
+        workspace; give the pin back with `ws['_pins'] -= 1` when the graph is dropped."""
+        ws = self._workspace(B, N, slot)
+        ws["_pins"] = ws.get("_pins", 0) + 1
+        return ws
+
+    def _wait_pending_join(self, ws):
+        """A deferred grouping (prepare_grouping(defer_join=True)) whose consumer never ran - an exception in between, a caller that only
+        wanted the ticket - leaves work on the side stream that reads new_xyz[0] and writes the deeper levels: every writer of the
+        grouping buffers waits for it first."""
+        pending = ws.pop("_join", None)
+        if pending is not None:
+            torch.cuda.current_stream(self.device).wait_event(pending)
 
     # ------------------------------------------------------------------ workspace (cached per batch/size)
     def _workspace(self, B, N, slot=0):
@@ -73,6 +100,7 @@ class Pointnet2EncoderHIP:
         xyz0 = pts[..., 0:3].contiguous()
         B, N, _ = xyz0.shape
         ws = self._workspace(B, N, slot)
+        self._wait_pending_join(ws)
         ws["_gen"] = next(_GENERATION)  # fps_idx / new_xyz are about to be overwritten: tickets for the previous contents die here
         st = stream_ptr()
         cfg = self.cfg
@@ -94,6 +122,8 @@ class Pointnet2EncoderHIP:
 
     def _ball_queries(self, ws, xyz0, B, N, levels=None):
         """Ball queries of every grouping level (they depend on the coordinates only) into ws['bq']; `levels`: only those levels."""
+        if levels is None:  # (a level-restricted call is prepare_grouping's own, which has just handled the pending join)
+            self._wait_pending_join(ws)
         ws["_gen"] = next(_GENERATION)  # every writer of the grouping buffers invalidates outstanding tickets
         st = stream_ptr()
         cfg = self.cfg
@@ -130,9 +160,7 @@ class Pointnet2EncoderHIP:
         the deeper levels and their ball queries go to a side stream and run UNDERNEATH the level-0 set abstraction (ball query, both
         chain kernels, the hoisted GEMM of level 1).  The workspace then carries the join event (`_join`), which forward(grouping=ws)
         waits for before its first use of a deeper level."""
-        pending = self._workspace(pts.shape[0], pts.shape[1], slot).pop("_join", None)
-        if pending is not None:  # a deferred grouping nobody consumed: its side work must not race the writes below
-            torch.cuda.current_stream(self.device).wait_event(pending)
+        self._wait_pending_join(self._workspace(pts.shape[0], pts.shape[1], slot))  # a deferred grouping nobody consumed
         cfg = self.cfg
         group_levels = [k for k, npnt in enumerate(cfg["npoints"]) if npnt is not None]
         if not (defer_join and 2 <= len(group_levels) <= 3 and pts.shape[1] <= 1024 and pts.is_cuda):
@@ -185,7 +213,7 @@ class Pointnet2EncoderHIP:
         return (ticket is not None and ticket["key"] == key and ticket["pts"]() is pts and ticket["version"] == pts._version
                 and ticket["shape"] == tuple(pts.shape) and ticket["ws"].get("_gen") == ticket["gen"])
 
-    MAX_PASS_GRAPHS = 8
+    MAX_PASS_GRAPHS = 8  # captured encoder passes kept per encoder (least recently used first)
 
     def encode(self, pts, grouping=None, use_graph=True):
         """The whole encoder pass of an AGENT call (GFObjectPose.extract_pts_feature) as one hipGraph replay per input shape:
@@ -198,23 +226,27 @@ class Pointnet2EncoderHIP:
         direct = (lambda: self.forward(pts, grouping=grouping)) if grouping is not None else (lambda: self._forward_with_grouping(pts))
         if not use_graph or not pts.is_cuda or pts.dtype != torch.float32 or torch.cuda.is_current_stream_capturing():
             return direct()  # (wrong device / dtype: the launch-by-launch path raises what it always raised)
-        if not hasattr(self, "_pass_graphs"):
-            self._pass_graphs = {}
+        # (the id() of `grouping` is part of the key: an entry with a graph keeps its `grouping` alive, so the id cannot be reused
+        # while the entry lives; a shape only SEEN so far is remembered by shape alone)
         key = (tuple(pts.shape), id(grouping) if grouping is not None else None)
         ent = self._pass_graphs.get(key)
         if ent is None:
-            if len(self._pass_graphs) >= self.MAX_PASS_GRAPHS:
-                self._pass_graphs.pop(next(iter(self._pass_graphs)))
-            self._pass_graphs[key] = {"graph": None}
-            return direct()
-        self._pass_graphs[key] = self._pass_graphs.pop(key)  # most recently used last
-        if ent["graph"] is None:
+            seen = (tuple(pts.shape), grouping is not None)
+            if seen not in self._seen_once:
+                # first call of a shape: launch by launch (a shape that never returns never pays a capture, and - kept apart from the
+                # captured graphs - never evicts one: with more shapes in rotation than the cache holds, a shape is simply captured
+                # again when it comes back, instead of every newcomer throwing out a live graph)
+                self._seen_once[seen] = True
+                return direct()
             buf = pts[..., 0:3].contiguous().clone()
+            B, N = buf.shape[0], buf.shape[1]
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self.forward(buf, grouping=grouping) if grouping is not None else self._forward_with_grouping(buf)
-            ent.update(graph=g, buf=buf, out=out, grouping=grouping)  # `grouping` is kept alive: its id() is part of the key
+            # `grouping` is kept alive (its id() is part of the key); the workspace the replay writes into is pinned
+            ent = {"graph": g, "buf": buf, "out": out, "grouping": grouping, "pinned": [self.pin_workspaces(B, N, 0)]}
+            self._pass_graphs[key] = ent
         ent["buf"].copy_(pts[..., 0:3])
         if grouping is None:
             ent["out"][1]["_gen"] = next(_GENERATION)  # the replay rewrites the grouping buffers: tickets for the previous contents die here
@@ -244,6 +276,8 @@ class Pointnet2EncoderHIP:
             src = grouping
         else:
             src = ws
+            if not centres_done:
+                self._wait_pending_join(ws)
             # ---- furthest point sampling + gather for every level
             if not centres_done:
                 self.sample_centres(pts, slot)

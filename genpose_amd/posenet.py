@@ -13,12 +13,15 @@ and every cloud owns K consecutive pose rows - this is how PoseNet.pred_func avo
 import torch
 
 from .encoder import Pointnet2EncoderHIP
+from .lru import ShapeCache
 from .samplers import ODESampler, PCSampler
 from .scorenet import ScoreNetHIP
 from .sde import SIGMA_MAX, SIGMA_MIN
 
 
 class GFObjectPose:
+    MAX_SAMPLERS = 8  # distinct (sampler, B, K, steps ...) geometries kept alive
+
     def __init__(self, cfg, prior_fn, marginal_prob_fn, sde_fn, sampling_eps, T):
         self.cfg = cfg
         self.device = torch.device(cfg.device)
@@ -36,7 +39,10 @@ class GFObjectPose:
                     raise NotImplementedError(f"{k}='{getattr(cfg, k)}' (only the shipped default '{v}')")
         self.pts_encoder = None
         self.pose_score_net = None
-        self._samplers = {}
+        # samplers (captured launch chains + noise / solver-state buffers) and pinned staging buffers per batch geometry: bounded,
+        # least recently used first (lru.py) - a ragged tail per category / a new object count per image must not accumulate
+        self._samplers = ShapeCache(self.MAX_SAMPLERS)
+        self._staging = ShapeCache(self.MAX_SAMPLERS)
         self.training = False
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -45,7 +51,7 @@ class GFObjectPose:
         params = getattr(self.cfg, "pointnet2_params", "light")
         self.pts_encoder = Pointnet2EncoderHIP(sd, self.device, params, arith=getattr(self.cfg, "dist_arith", None))
         self.pose_score_net = ScoreNetHIP(sd, self.device)
-        self._samplers = {}
+        self._samplers.clear()
         return self
 
     def eval(self):
@@ -96,10 +102,8 @@ class GFObjectPose:
         if cpu.is_cuda:
             return cpu.float()
         key = tuple(cpu.shape)
-        st = self._staging.get(key) if hasattr(self, "_staging") else None
+        st = self._staging.get(key)
         if st is None:
-            if not hasattr(self, "_staging"):
-                self._staging = {}
             st = self._staging[key] = (torch.empty(key, dtype=torch.float32).pin_memory(), torch.cuda.Event())
             st[1].record()
         pinned, ev = st

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import reward, rotation
+from .lru import ShapeCache
 
 
 def make_batch_sample(pts):
@@ -141,7 +142,11 @@ class _FrameGraphs:
         self.share = snet.pts_encoder.grouping_key() == enet.pts_encoder.grouping_key()
         self.side = torch.cuda.Stream(dev)
         self.ev_a, self.ev_e = torch.cuda.Event(), torch.cuda.Event()
-        self._a, self._b = {}, {}
+        # per object count of a frame: bounded (lru.py); a dropped entry gives its encoder workspaces back to their eviction order
+        self._a = ShapeCache(self.MAX_SHAPES, on_evict=lambda k, ent: [ws.__setitem__("_pins", ws["_pins"] - 1) for ws in ent[4]])
+        self._b = ShapeCache(self.MAX_SHAPES)
+
+    MAX_SHAPES = 8
 
     SLOT = "frame-graphs"  # the replays write into encoder workspaces of their own: no ticket of the agent path ever points at them
 
@@ -172,8 +177,11 @@ class _FrameGraphs:
             ge = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ge, stream=self.side):
                 cvec_e = self._energy_body(buf, grouping)
-            ent = self._a[key] = (ga, ge, buf, (centre, cvec_s, cvec_e))
-        ga, ge, buf, outs = ent
+            # the replays write into encoder workspaces that were allocated outside the captures: pinned while these graphs live
+            n, N = int(buf.shape[0]), int(buf.shape[1])
+            pinned = [self.snet.pts_encoder.pin_workspaces(n, N, self.SLOT), self.enet.pts_encoder.pin_workspaces(n, N, self.SLOT)]
+            ent = self._a[key] = (ga, ge, buf, (centre, cvec_s, cvec_e), pinned)
+        ga, ge, buf, outs, _ = ent
         cur.wait_event(self.ev_e)  # the previous frame's A' (side stream) has finished reading `buf`, which is about to change
         buf.copy_(pts)
         ga.replay()
@@ -254,8 +262,12 @@ class TrackingRunner:
             centre = sample["pts_center"]
         with _one_cpu_thread():
             noised = add_noise_to_RT(gt_RT.float().cpu(), draws=noise_draws)  # drawn every frame (:302), whether or not it is used
-        if self.buffer["pred_sRT"] is not None and list(model_names) == self.buffer["model_name"]:
-            init_sRT = self.buffer["pred_sRT"].float()  # every object continues from the previous frame: nothing to upload, one tensor
+        if (self.buffer["pred_sRT"] is not None and list(model_names) == self.buffer["model_name"]
+                and len(set(model_names)) == len(model_names)):
+            # every object continues from the previous frame: nothing to upload, one tensor.  (Unique names only: the reference looks a
+            # name up with list.index (evaluation_tracking.py:303-307) - two objects with the SAME name both get the first one's pose,
+            # which the general branch below reproduces.)
+            init_sRT = self.buffer["pred_sRT"].float()
         else:
             init_sRT = noised.to(dev)
             for i, name in enumerate(model_names):
@@ -283,7 +295,8 @@ class TrackingRunner:
             average_sRT = rotation.quat_trans_to_RT(r["avg_pose"])
             sorted_RTs = rotation.pose9_to_RT(r["sorted_poses"])
         self.buffer = {"model_name": list(model_names), "pred_sRT": average_sRT}
-        return {"init_x": init_x, "pred_pose": pred, "energy": energy, "sorted_RTs": sorted_RTs, "average_sRT": average_sRT}
+        # (the caller gets its own copy of the aggregated poses: the buffer's tensor is the next frame's warm start)
+        return {"init_x": init_x, "pred_pose": pred, "energy": energy, "sorted_RTs": sorted_RTs, "average_sRT": average_sRT.clone()}
 
 
 class MultiSequenceTracker:
@@ -315,8 +328,8 @@ class MultiSequenceTracker:
         frame this step).  Returns one TrackingRunner-style dict per sequence (None where there was no frame).
         prior (tests): per sequence, the prior draw [n_i*K,9] exactly as `prior_fn((n_i*K, 9), T=T0)` returns it (already scaled by
         sigma(T0)) - it stands in for prior_fn, unlike the `prior_noise` of the pipeline predictors (standard-normal draws).
-        The returned tensors are slices of the step's own result tensors, and `average_sRT` is also the next step's warm start: read them,
-        clone before editing in place."""
+        The returned tensors are slices of the step's own result tensors; `average_sRT` is a copy (the tracker keeps the original as the
+        next step's warm start, so an in-place edit by the caller - a unit conversion, a scale - cannot reach it)."""
         from .samplers import ODESampler
         net = self.score_agent.net
         net._need_weights()
@@ -335,7 +348,9 @@ class MultiSequenceTracker:
         draws_all = None if noise_draws is None else [torch.cat([noise_draws[i][d] for i in live], dim=0) for d in range(4)]
         with _one_cpu_thread():
             noised = add_noise_to_RT(gt_all, draws=draws_all)  # drawn every frame (evaluation_tracking.py:302), whether or not it is used
-        if self._prev is not None and self._prev[0] == live and all(list(frames[i][1]) == self.buffers[i]["model_name"] for i in live):
+        if (self._prev is not None and self._prev[0] == live
+                and all(list(frames[i][1]) == self.buffers[i]["model_name"] and len(set(frames[i][1])) == len(frames[i][1]) for i in live)):
+            # (unique names per frame only: duplicates go through list.index below, first match, as evaluation_tracking.py:303-307)
             # every object of every sequence continues from the previous step, in the same order: the previous aggregated poses ARE the
             # initial poses - nothing to upload, no index tensors (their pageable host-to-device copies wait for the stream)
             init_sRT = self._prev[1]
@@ -383,11 +398,12 @@ class MultiSequenceTracker:
         average_sRT = rotation.quat_trans_to_RT(r["avg_pose"])
         sorted_RTs = rotation.pose9_to_RT(r["sorted_poses"])
         lo = 0
+        for_caller = average_sRT.clone()  # one small device-side copy, no synchronisation
         for q, i in enumerate(live):
             sl = slice(lo, lo + counts[q])
             lo += counts[q]
             self.buffers[i] = {"model_name": list(frames[i][1]), "pred_sRT": average_sRT[sl]}  # (views of this step's own tensor)
-            out[i] = {"init_x": init_x[sl], "pred_pose": pred[sl], "energy": energy[sl], "sorted_RTs": sorted_RTs[sl], "average_sRT": average_sRT[sl],
+            out[i] = {"init_x": init_x[sl], "pred_pose": pred[sl], "energy": energy[sl], "sorted_RTs": sorted_RTs[sl], "average_sRT": for_caller[sl],
                       "nfev": int(smp.group_stats[q]["nfev"])}
         self._prev = (live, average_sRT)
         return out

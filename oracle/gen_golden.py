@@ -122,11 +122,17 @@ def gen_g1_g2(ns, arith=None):
         g["odd_bq"] = P.ball_query(0.05, 5, odd.contiguous(), odd[:, :50].contiguous()).numpy().astype(np.int16)
         # three_nn / three_interpolate (north_star lists them; the encoder does not reach them): the other two sites of the contraction
         unknown, known = xyz[:2, :300].contiguous(), xyz[:2, 300:364].contiguous()
-        d, i3 = P.three_nn(unknown, known)
-        w = (1.0 / (d + 1e-8))
-        w = (w / w.sum(dim=2, keepdim=True)).contiguous()
+        # ThreeNN.forward returns torch.sqrt(dist2) (pointnet2_utils.py:99) and a vectorised host sqrt is not the same bits on every CPU:
+        # the fixture keeps dist2 itself, captured with torch.sqrt stubbed to the identity for this one call
+        _sqrt, torch.sqrt = torch.sqrt, (lambda t: t)
+        try:
+            d2, i3 = P.three_nn(unknown, known)
+        finally:
+            torch.sqrt = _sqrt
+        w = 1.0 / (d2.double().sqrt() + 1e-8)
+        w = (w / w.sum(dim=2, keepdim=True)).float().contiguous()
         feats = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 7, 64)).astype(np.float32))
-        g["nn_dist"], g["nn_idx"] = d.numpy(), i3.numpy().astype(np.int16)
+        g["nn_dist2"], g["nn_idx"] = d2.numpy(), i3.numpy().astype(np.int16)
         g["interp_feats"], g["interp_w"] = feats.numpy(), w.numpy()
         g["interp_out"] = P.three_interpolate(feats, i3, w).numpy()
     name = "g1_g2_ops.npz" if arith == pn2_oracle.DEFAULT_ARITH else f"g1_g2_ops_arith{arith}.npz"

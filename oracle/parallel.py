@@ -1,0 +1,82 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (same rule as the rest of oracle/: tests, smoke and bench.py's cpu_baseline leg only).
+
+The oracle's encoder over MANY clouds, for the tests that check the HIP path at the sizes the configs are quoted on (hundreds of
+clouds): clouds are independent units, so
+  * results are cached per (weights, convention, cloud bytes) for the life of the process - three tests that ask for the same 448
+    synthetic clouds pay once;
+  * missing clouds are computed in slices by a small pool of worker PROCESSES (spawned, CPU only, a few torch threads each): on the
+    GPU box's 256 host cores one process with 256 threads is slower than 8 threads (the slices are small convolutions), so the cores
+    are used side by side instead.
+Same function, same arithmetic, same slices' worth of work as go.encoder_forward called in a loop - only where it runs differs.
+"""
+import atexit
+import hashlib
+import os
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+_cache = {}
+_pool = None
+_WORKER = {}
+
+
+def _plan():
+    n = os.cpu_count() or 8
+    threads = 8 if n >= 16 else max(1, n)
+    workers = max(1, min(16, n // threads))
+    return workers, threads
+
+
+def _init(threads):
+    import torch
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+
+
+def _encode_slice(mode, seed, arith, pts):
+    import torch
+    from . import genpose_oracle as go
+    from . import pn2_oracle as ops
+    key = (mode, seed)
+    if key not in _WORKER:
+        _WORKER[key] = go.make_state_dict(seed, mode)
+    with ops.use_arith(arith):
+        return go.encoder_forward(_WORKER[key], torch.from_numpy(pts)).numpy()
+
+
+def pool():
+    global _pool
+    if _pool is None:
+        import multiprocessing as mp
+        workers, threads = _plan()
+        _pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"), initializer=_init, initargs=(threads,))
+        atexit.register(shutdown)
+    return _pool
+
+
+def shutdown():
+    global _pool
+    if _pool is not None:
+        _pool.shutdown(wait=False, cancel_futures=True)
+        _pool = None
+
+
+def encoder_features(mode, pts, seed=0, arith=None, slice_clouds=16):
+    """go.encoder_forward(go.make_state_dict(seed, mode), pts) for pts [B,1024,3] (numpy or CPU tensor) -> numpy [B,1024]."""
+    from . import pn2_oracle as ops
+    arith = arith or ops.current_arith()
+    pts = np.ascontiguousarray(pts.numpy() if hasattr(pts, "numpy") else pts, dtype=np.float32)
+    keys = [(mode, seed, arith, hashlib.sha1(pts[i].tobytes()).hexdigest()) for i in range(pts.shape[0])]
+    missing = [i for i, k in enumerate(keys) if k not in _cache]
+    if missing:
+        chunks = [missing[s:s + slice_clouds] for s in range(0, len(missing), slice_clouds)]
+        if len(chunks) == 1 and _pool is None:  # a handful of clouds: not worth starting workers
+            outs = [_encode_slice(mode, seed, arith, pts[chunks[0]])]
+        else:
+            futs = [pool().submit(_encode_slice, mode, seed, arith, pts[c]) for c in chunks]
+            outs = [f.result() for f in futs]
+        for c, o in zip(chunks, outs):
+            for i, row in zip(c, o):
+                _cache[keys[i]] = row
+    return np.stack([_cache[k] for k in keys])

@@ -10,8 +10,18 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def host_threads():
+    """Intra-op threads for the CPU side of the tests (the oracle).  torch's default is one thread per host core - 256 on the GPU box -
+    and on the oracle's small convolutions / 3 200 - 12 800-row GEMMs that is 20 - 90x SLOWER than 16 (measured there, round 5:
+    32-cloud encoder slice 25 s vs 1.4 s; one 12 800-row score evaluation 4.8 s vs 55 ms; profiles/r5_oracle_host_timing.txt)."""
+    return max(1, min(int(os.environ.get("GP_TEST_THREADS", "16")), os.cpu_count() or 16))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_threads()))  # inherited by every process the tests spawn
+    import torch
+    torch.set_num_threads(host_threads())
 
 
 def pytest_collection_modifyitems(config, items):

@@ -348,3 +348,28 @@ def test_bench_spawns_the_documented_launch_line(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["GP_BENCH_LAUNCH"] == "self" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_shape_cache_evicts_least_recently_used_and_skips_pins():
+    """lru.ShapeCache: the bounded per-shape caches of the host side (samplers, staging buffers, encoder workspaces, captured passes)."""
+    from genpose_amd.lru import ShapeCache
+    ev = []
+    c = ShapeCache(3, can_evict=lambda v: not v.get("pin"), on_evict=lambda k, v: ev.append(k))
+    c["a"] = {"pin": True}
+    c["b"] = {}
+    c["c"] = {}
+    assert c.get("b") is not None  # b is now the most recently used
+    c["d"] = {}
+    assert list(c.keys()) == ["a", "b", "d"] and ev == ["c"]  # a is pinned; c was the least recently used unpinned entry
+    c["e"] = {}
+    assert list(c.keys()) == ["a", "d", "e"] and ev == ["c", "b"]
+    assert "a" in c and c["a"]["pin"] and len(c) == 3 and c.get("zzz") is None
+    with pytest.raises(KeyError):
+        c["zzz"]
+    c["f"] = {"pin": True}
+    c["g"] = {"pin": True}
+    assert all(v.get("pin") for v in c.values())  # nothing evictable is left: the cache exceeds its soft capacity rather than drop a pin
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    net = PoseNet(get_config(device="cpu")).net
+    assert isinstance(net._samplers, ShapeCache) and net._samplers.capacity == net.MAX_SAMPLERS == 8

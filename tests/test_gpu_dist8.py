@@ -72,17 +72,29 @@ def _coupled_pc(sa, ea, shard_ids, group):
 
 
 def _worker(rank, port, out_dir):
+    import time
+    torch.set_num_threads(4)  # eight processes share the host: the default (one thread per core, each) made this fixture 160 s of thrashing
+    marks = [("start", time.time())]
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    marks.append(("process group", time.time()))
     try:
         torch.cuda.set_device(0)
         from genpose_amd.dist import ShardedInference
         clouds = torch.from_numpy(np.load(os.path.join(out_dir, "clouds.npy"))).cuda()
         sa, ea = _agents("ode", None)
+        torch.cuda.synchronize()
+        marks.append(("device context + ODE agents", time.time()))
         out = ShardedInference(_drop_in(sa, ea, [rank]))(clouds)
+        torch.cuda.synchronize()
+        marks.append(("sharded drop-in sequence", time.time()))
         sp, ep = _agents("pc", NSTEPS)
         outc = ShardedInference(_coupled_pc(sp, ep, [rank], dist.group.WORLD))(clouds)
         torch.cuda.synchronize()
+        marks.append(("coupled PC-100", time.time()))
+        if rank == 0:
+            with open(os.path.join(out_dir, "worker0_times.txt"), "w") as f:
+                f.write(", ".join(f"{n} {t - marks[i][1]:.1f} s" for i, (n, t) in enumerate(marks[1:])))
         if rank == WORLD - 1:  # every rank holds the full result set: take it from the LAST rank
             np.savez(os.path.join(out_dir, "sharded.npz"), **{k: v.cpu().numpy() for k, v in out.items()},
                      **{"c_" + k: v.cpu().numpy() for k, v in outc.items()})
@@ -99,7 +111,15 @@ def sharded(tmp_path_factory):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import time
+    t0 = time.time()
     mp.spawn(_worker, args=(port, d), nprocs=WORLD, join=True)
+    line = f"[dist8 fixture] {WORLD} workers on one device: {time.time() - t0:.1f} s; rank 0: {open(os.path.join(d, 'worker0_times.txt')).read()}"
+    print(line)
+    scratch = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(scratch):
+        with open(os.path.join(scratch, "dist8_fixture_times.txt"), "w") as f:
+            f.write(line + "\n")
     return torch.from_numpy(np.load(os.path.join(d, "clouds.npy"))).cuda(), dict(np.load(os.path.join(d, "sharded.npz")))
 
 

@@ -82,7 +82,7 @@ def test_fps_bq_golden(pn2, golden, arith):
     i3 = torch.empty(2, 300, 3, dtype=torch.int32, device="cuda")
     pn2.three_nn_wrapper(2, 300, 64, dev(unk), dev(kn), d2, i3)
     assert np.array_equal(i3.cpu().numpy(), g["nn_idx"].astype(np.int32))
-    assert np.array_equal(torch.sqrt(d2.cpu()).numpy(), g["nn_dist"])  # pointnet2_utils.py:99 returns torch.sqrt(dist2) (host tensor there)
+    assert np.array_equal(d2.cpu().numpy(), g["nn_dist2"])
     out = torch.empty(2, 7, 300, device="cuda")
     pn2.three_interpolate_wrapper(2, 7, 64, 300, dev(g["interp_feats"]), i3, dev(g["interp_w"]), out)
     assert np.array_equal(out.cpu().numpy(), g["interp_out"])

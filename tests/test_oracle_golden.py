@@ -74,7 +74,7 @@ def _check_g1_g2(g):
     unk, kn = np.ascontiguousarray(g["clouds"][:2, :300]), np.ascontiguousarray(g["clouds"][:2, 300:364])
     d2, i3 = ops.three_nn(unk, kn)
     assert np.array_equal(i3, g["nn_idx"].astype(np.int32))
-    assert np.array_equal(torch.sqrt(torch.from_numpy(d2)).numpy(), g["nn_dist"])  # pointnet2_utils.py:99 returns torch.sqrt(dist2)
+    assert np.array_equal(d2, g["nn_dist2"])
     assert np.array_equal(ops.three_interpolate(g["interp_feats"], i3, g["interp_w"]), g["interp_out"])
 
 
