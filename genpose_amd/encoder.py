@@ -26,6 +26,16 @@ from .weights import EncoderWeights
 _GENERATION = itertools.count(1)  # process-wide: every write of a workspace's grouping buffers gets a generation no other write has
 
 
+def _unpinned(ws):
+    return ws.get("_pins", 0) == 0
+
+
+def _unpin_entry(key, ent):
+    """A captured pass leaves the cache: the workspaces its replays wrote into return to the eviction order."""
+    for ws in ent.get("pinned", ()):
+        ws["_pins"] = ws.get("_pins", 1) - 1
+
+
 class Pointnet2EncoderHIP:
     def __init__(self, state_dict, device="cuda", params="light", prefix="pts_encoder.", arith=None):
         """arith: contraction convention of the squared distances in furthest point sampling and the ball queries ('A' | 'B' | 'C',
@@ -37,15 +47,11 @@ class Pointnet2EncoderHIP:
         self.out_dim = self.w.out_dim
         # workspaces (~1.5 MB per cloud) per (batch, points, slot): least recently used first, except those a captured graph writes
         # into (`_pins`: taken by whoever captures, given back when that graph is dropped)
-        self._ws = ShapeCache(self.MAX_WORKSPACES, can_evict=lambda ws: ws.get("_pins", 0) == 0)
-        self._pass_graphs = ShapeCache(self.MAX_PASS_GRAPHS, on_evict=lambda k, ent: self._unpin(ent))
+        self._ws = ShapeCache(self.MAX_WORKSPACES, can_evict=_unpinned)
+        self._pass_graphs = ShapeCache(self.MAX_PASS_GRAPHS, on_evict=_unpin_entry)  # (no closure over self: no reference cycle)
         self._seen_once = ShapeCache(4 * self.MAX_PASS_GRAPHS)
 
     MAX_WORKSPACES = 12
-
-    def _unpin(self, ent):
-        for ws in ent.get("pinned", ()):
-            ws["_pins"] = ws.get("_pins", 1) - 1
 
     def pin_workspaces(self, B, N, slot=0):
         """For whoever CAPTURES launches of this encoder in a hipGraph: the workspace of that geometry stays out of the eviction order

@@ -120,6 +120,11 @@ def add_noise_to_RT(RT, r=5.0, t=0.03, draws=None):
     return out
 
 
+def _unpin_frame_entry(key, ent):
+    for ws in ent[4]:
+        ws["_pins"] -= 1
+
+
 class _FrameGraphs:
     """hipGraphs of the launch sequences of a tracking frame that need no host decision, keyed by the clouds' shape:
       A   clouds [n,1024,3] -> centres, the SCORE model's per-cloud embedding: grouping (furthest point sampling with its deeper levels on a
@@ -143,7 +148,7 @@ class _FrameGraphs:
         self.side = torch.cuda.Stream(dev)
         self.ev_a, self.ev_e = torch.cuda.Event(), torch.cuda.Event()
         # per object count of a frame: bounded (lru.py); a dropped entry gives its encoder workspaces back to their eviction order
-        self._a = ShapeCache(self.MAX_SHAPES, on_evict=lambda k, ent: [ws.__setitem__("_pins", ws["_pins"] - 1) for ws in ent[4]])
+        self._a = ShapeCache(self.MAX_SHAPES, on_evict=_unpin_frame_entry)
         self._b = ShapeCache(self.MAX_SHAPES)
 
     MAX_SHAPES = 8
