@@ -12,6 +12,7 @@ SO_PATH = os.environ.get("GENPOSE_HIP_LIB") or os.path.join(_HERE, "lib", "libge
 
 c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 P = c_void_p
+PLAN_HEADSPLIT = 0x100  # GP_PLAN_HEADSPLIT (include/genpose_hip.h): OR-ed onto a 16-row tile plan = three workgroups per tile, one head each
 
 
 class GpScoreNet(ctypes.Structure):
@@ -72,6 +73,7 @@ SIGNATURES = {
     "gp_rk45_phase": [c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
     "gp_rk45_phase_grouped": [c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
     "gp_rk45_plan_rows": [c_int, c_int, c_int, c_int],
+    "gp_plan_headsplit_pays": [c_int],
     "gp_rk45_phase_model": [c_int, c_int, P, c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5
                            + [c_int, c_int, P, P, c_int, P],
     "gp_rk45_set_dense_grouped": [c_int, P, P, c_int, P, P],

@@ -86,6 +86,10 @@ struct OdeArgs {
     // ext_rows = rows of a group over all ranks.  null: the controller reduces the local partials itself.
     double *ext_sums;
     int ext_rows;
+    // head-split plan (GP_PLAN_HEADSPLIT; score model, 16-row tiles, the latency regime): hsplit = 3 workgroups per tile, workgroup 3 t + h
+    // evaluates head h of tile t and owns components 3 h .. 3 h + 2 of its rows; every count above (nblocks, bpg, the ragged tables) stays
+    // in TILES, the partial sums are laid out [3][nblocks * hsplit], one per workgroup.  1 = one workgroup per tile.
+    int hsplit;
 };
 
 // MODEL of the right-hand side (the same Dormand-Prince driver integrates all three):
@@ -101,12 +105,12 @@ struct OdeModel {
 
 // which group / rows does this workgroup serve
 template <int P>
-__device__ __forceinline__ void ode_block(const OdeArgs &a, int &grp, int &row0, int &row_end) {
+__device__ __forceinline__ void ode_block(const OdeArgs &a, int tile, int &grp, int &row0, int &row_end) {
     if (a.blk_info) {
-        const int *bi = a.blk_info + 3 * blockIdx.x;
+        const int *bi = a.blk_info + 3 * tile;
         grp = bi[0], row0 = bi[1], row_end = bi[2];
     } else {
-        grp = blockIdx.x / a.bpg, row0 = blockIdx.x * P, row_end = a.nrows;
+        grp = tile / a.bpg, row0 = tile * P, row_end = a.nrows;
     }
 }
 
@@ -126,14 +130,21 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 // Fused stage kernel.  STAGE 1..6: Runge-Kutta stage;  STAGE 0: f0 = fun(t0, y0) (+ d0,d1 partials);
 // STAGE 7: f1 = fun(t0 + h0*dir, y0 + h0*dir*f0) (+ d2 partial).
 // One stage for the workgroup's tile.  Returns false when the workgroup has nothing to do (padding workgroup, finished solve).
-template <int P, int STAGE, int MODEL>
+// SPLIT: the head-split plan (OdeArgs::hsplit = 3): this workgroup evaluates ONE head of its tile and owns that head's three state
+// components - it computes the stage input of all nine (the network needs them; element-local arithmetic, identical in the three
+// workgroups of a tile), and commits / stores / sums only its own.  What a stage reads of earlier stages (K_q of all nine components)
+// was written by other workgroups: the stages of an attempt are separate launches under this plan.
+template <int P, int STAGE, int MODEL, bool SPLIT = false>
 __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_scorenet &net, float *lds, double *sh) {
     static_assert(MODEL == 0 || P == gp_bwd::DP, "the backward pass runs on 16-row tiles");
+    static_assert(!SPLIT || (MODEL == 0 && P == 16), "head-split: score model, 16-row tiles");
     using L = TrunkLds<P, OdeModel<MODEL>::BWD>;
     constexpr int NC = OdeModel<MODEL>::NC;
     const int tid = threadIdx.x;
+    const int tile = SPLIT ? blockIdx.x / 3 : blockIdx.x, hsel = SPLIT ? blockIdx.x - 3 * tile : 0;
+    auto owned = [&](int j) { return !SPLIT || j / 3 == hsel; };
     int grp, row0, rend;
-    ode_block<P>(a, grp, row0, rend);
+    ode_block<P>(a, tile, grp, row0, rend);
     if (row0 >= rend) return false;  // padding workgroup of a ragged launch (tables sized for a capacity)
     Rk45State *st = a.st + grp;
     if (STAGE >= 1 && STAGE <= 6 && st->status != 0) return false;
@@ -158,7 +169,7 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
         const size_t ge = (size_t)r * NC + j;
         const bool commit = STAGE == 1 && st->last_accepted;
         double yv = commit ? a.ynew[ge] : a.y[ge];
-        if (commit && live) {
+        if (commit && live && owned(j)) {
             // commit the previous accepted step for this element (element-local: no other thread touches it)
             a.y[ge] = yv;
             a.K[ge] = a.K[6 * n + ge];
@@ -171,7 +182,7 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
                 dy += kq * DP_A[STAGE][q];
             }
             yv = yv + dy * h;  // rk.py: dy = dot(K[:s].T, a[:s]) * h ; y + dy   (stage 6: y + h * dot(K[:-1].T, B))
-            if (STAGE == 6 && live) a.ynew[ge] = yv;
+            if (STAGE == 6 && live && owned(j)) a.ynew[ge] = yv;
         } else if (STAGE == 7) {
             yv = yv + st->h0 * st->direction * a.K[ge];  // common.py: y1 = y0 + h0 * direction * f0
         }
@@ -183,7 +194,7 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
     const float *F;
     int ldf;
     if constexpr (MODEL == 0) {
-        trunk_ftheta<P>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre);
+        trunk_ftheta<P, false, TrunkNoEmit, SPLIT>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre, TrunkNoEmit(), hsel);
         F = lds + L::OFF_H1, ldf = L::LDH;
     } else {
         F = gp_bwd::score_vjp_tile<MODEL == 1 ? gp_bwd::ENERGY : gp_bwd::SCORE_DIV>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre, sigma);
@@ -193,7 +204,7 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
     double acc0 = 0.0, acc1 = 0.0;
     for (int e = tid; e < P * NC; e += TrunkCfg<P>::NT) {
         const int r = e / NC, j = e - r * NC;
-        if (row0 + r >= rend) continue;
+        if (row0 + r >= rend || !owned(j)) continue;
         const size_t ge = (size_t)(row0 + r) * NC + j;
         const float rhs = MODEL == 0 ? F[r * ldf + j] / (sigma + 1e-7f) : F[r * ldf + j];  // score component (j = 9: divergence estimate)
         const double kv = 0.0 - (0.5 * g2) * (double)rhs;  // drift - 0.5 * g^2 * score (samplers.py:198; :83-86 for the log-density)
@@ -223,17 +234,17 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
         if (tid == 0) a.partials[blockIdx.x] = s0;
         if (STAGE == 0) {
             const double s1 = block_sum(acc1, sh);
-            if (tid == 0) a.partials[a.nblocks + blockIdx.x] = s1;
+            if (tid == 0) a.partials[a.nblocks * a.hsplit + blockIdx.x] = s1;
         }
     }
     return true;
 }
 
-template <int P, int STAGE, int MODEL>
+template <int P, int STAGE, int MODEL, bool SPLIT = false>
 __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_stage_kernel(OdeArgs a, gp_scorenet net) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double sh[8];
-    rk45_stage_body<P, STAGE, MODEL>(a, net, lds, sh);
+    rk45_stage_body<P, STAGE, MODEL, SPLIT>(a, net, lds, sh);
 }
 
 // The six stages of an attempt in ONE launch, for the latency regime (16-row tiles: a tracking frame's solve is ~40 stage launches of
@@ -492,8 +503,9 @@ __device__ void publish_attempt(Rk45State *st) {
 __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
     __shared__ double sh[8];
     Rk45State *st = a.st + blockIdx.x;  // one workgroup per group
-    const int blk0 = a.grp_info ? a.grp_info[4 * blockIdx.x] : blockIdx.x * a.bpg;
-    const int nblk = a.grp_info ? a.grp_info[4 * blockIdx.x + 1] : a.bpg;
+    // (head-split plan: hsplit partial sums per tile, consecutive - a group's partials stay one contiguous range)
+    const int blk0 = (a.grp_info ? a.grp_info[4 * blockIdx.x] : blockIdx.x * a.bpg) * a.hsplit;
+    const int nblk = (a.grp_info ? a.grp_info[4 * blockIdx.x + 1] : a.bpg) * a.hsplit;
     const int grows = a.grp_info ? a.grp_info[4 * blockIdx.x + 2] : a.rows_per_group;
     const double *part = a.partials + blk0;
     if (grows <= 0) {  // padding group of a ragged launch: nothing to integrate
@@ -504,7 +516,7 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
     const int ng = gridDim.x;
     if (mode == 0) {
         const double s0 = a.ext_sums ? a.ext_sums[blockIdx.x] : sum_partials(part, nblk, sh);
-        const double s1 = a.ext_sums ? a.ext_sums[ng + blockIdx.x] : sum_partials(part + a.nblocks, nblk, sh);
+        const double s1 = a.ext_sums ? a.ext_sums[ng + blockIdx.x] : sum_partials(part + a.nblocks * a.hsplit, nblk, sh);
         if (threadIdx.x == 0) {
             const double d0 = sqrt(s0) / sqrt(nn), d1 = sqrt(s1) / sqrt(nn);  // norm(x) = |x|_2 / sqrt(size)
             const double interval = fabs(st->t_bound - st->t);
@@ -581,10 +593,10 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
 // Sharded batch: this rank's per-group sums of the stage kernels' partials (fixed order) -> ext_sums, for the caller's all-reduce.
 __global__ __launch_bounds__(256) void rk45_group_sums_kernel(OdeArgs a, int nsums) {
     __shared__ double sh[8];
-    const int blk0 = a.grp_info ? a.grp_info[4 * blockIdx.x] : blockIdx.x * a.bpg;
-    const int nblk = a.grp_info ? a.grp_info[4 * blockIdx.x + 1] : a.bpg;
+    const int blk0 = (a.grp_info ? a.grp_info[4 * blockIdx.x] : blockIdx.x * a.bpg) * a.hsplit;
+    const int nblk = (a.grp_info ? a.grp_info[4 * blockIdx.x + 1] : a.bpg) * a.hsplit;
     for (int w = 0; w < nsums; ++w) {
-        const double s = sum_partials(a.partials + (size_t)w * a.nblocks + blk0, nblk, sh);
+        const double s = sum_partials(a.partials + (size_t)w * a.nblocks * a.hsplit + blk0, nblk, sh);
         if (threadIdx.x == 0) a.ext_sums[(size_t)w * gridDim.x + blockIdx.x] = s;
     }
 }
@@ -634,7 +646,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_finish_kernel(OdeArgs a,
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     int grp, row0, rend;
-    ode_block<P>(a, grp, row0, rend);
+    ode_block<P>(a, blockIdx.x, grp, row0, rend);
     if (row0 >= rend) return;
     const Rk45State *st = a.st + grp;
     const double *yfin = st->last_accepted ? a.ynew : a.y;
@@ -749,7 +761,8 @@ int set_lds_attr(K kern, size_t lds) {
 
 // CHAIN: the stage kernels run in the chain form (a.bpg / a.nblocks count 128-row workgroups); the denoising evaluation of phase 5
 // stays on P-row tiles with its own workgroup count
-template <int P, int MODEL, bool CHAIN = false>
+// SPLIT: the head-split plan (three workgroups per 16-row tile, one head each; OdeArgs::hsplit == 3): every stage is a launch of its own
+template <int P, int MODEL, bool CHAIN = false, bool SPLIT = false>
 static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double *traj, int traj_cap, double t0, double t_bound, double rtol,
                            double atol, double denoise_scale, int do_denoise, int nstates, const float *centre, double *x_out, hipStream_t st) {
     const size_t chain_lds = MODEL == 0 ? gp_chain::Cfg<2>::LDS_BYTES : gp_chain::CfgV<2>::LDS_BYTES;
@@ -764,20 +777,21 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
                 set_lds_attr(rk45_stage_chain_kernel<2, 6, MODEL>, chain_lds) || set_lds_attr(rk45_stage_chain_kernel<2, 7, MODEL>, chain_lds))
                 return GP_ELAUNCH;
         }
-        if (set_lds_attr(rk45_stage_kernel<P, 0, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 1, MODEL>, lds) ||
-            set_lds_attr(rk45_stage_kernel<P, 2, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 3, MODEL>, lds) ||
-            set_lds_attr(rk45_stage_kernel<P, 4, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 5, MODEL>, lds) ||
-            set_lds_attr(rk45_stage_kernel<P, 6, MODEL>, lds) || set_lds_attr(rk45_stage_kernel<P, 7, MODEL>, lds))
+        if (set_lds_attr(rk45_stage_kernel<P, 0, MODEL, SPLIT>, lds) || set_lds_attr(rk45_stage_kernel<P, 1, MODEL, SPLIT>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 2, MODEL, SPLIT>, lds) || set_lds_attr(rk45_stage_kernel<P, 3, MODEL, SPLIT>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 4, MODEL, SPLIT>, lds) || set_lds_attr(rk45_stage_kernel<P, 5, MODEL, SPLIT>, lds) ||
+            set_lds_attr(rk45_stage_kernel<P, 6, MODEL, SPLIT>, lds) || set_lds_attr(rk45_stage_kernel<P, 7, MODEL, SPLIT>, lds))
             return GP_ELAUNCH;
         if constexpr (MODEL != 2) {
             if (set_lds_attr(rk45_finish_kernel<P, MODEL>, lds)) return GP_ELAUNCH;
         }
-        if constexpr (!CHAIN && P == 16) {
+        if constexpr (!CHAIN && !SPLIT && P == 16) {
             if (set_lds_attr(rk45_attempt_kernel<P, MODEL>, lds)) return GP_ELAUNCH;
         }
         attr_done = true;
     }
-    const dim3 grid(a.nblocks), blk(TrunkCfg<P>::NT), blk1(256);
+    if ((a.hsplit == 3) != SPLIT) return GP_EINVAL;
+    const dim3 grid(a.nblocks * (SPLIT ? 3 : 1)), blk(TrunkCfg<P>::NT), blk1(256);
     const size_t n = (size_t)a.nrows * a.ncomp;
     // time embeddings of stage slots [lo, lo + n) of every group, behind the kernel that decided their times
     auto embed = [&](int lo, int n) {
@@ -791,7 +805,7 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
         if constexpr (CHAIN)
             hipLaunchKernelGGL((rk45_stage_chain_kernel<2, S, MODEL>), grid, dim3(gp_chain::NT), chain_lds, st, a, *net);
         else
-            hipLaunchKernelGGL((rk45_stage_kernel<P, S, MODEL>), grid, blk, lds, st, a, *net);
+            hipLaunchKernelGGL((rk45_stage_kernel<P, S, MODEL, SPLIT>), grid, blk, lds, st, a, *net);
     };
     switch (phase) {
         case 0:
@@ -828,7 +842,7 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             embed(1, 6);
             break;
         case 3:
-            if constexpr (!CHAIN && P == 16) {
+            if constexpr (!CHAIN && !SPLIT && P == 16) {
                 // latency regime: the six stages of the attempt as ONE launch (rk45_attempt_kernel)
                 hipLaunchKernelGGL((rk45_attempt_kernel<P, MODEL>), grid, blk, lds, st, a, *net);
             } else {
@@ -862,7 +876,7 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
             if constexpr (MODEL == 2) {
                 hipLaunchKernelGGL(rk45_copy_final_kernel, dim3(32, a.ngroups), blk1, 0, st, a, x_out);
             } else {
-                OdeArgs af = a;
+                OdeArgs af = a;  // (the denoising evaluation runs on whole tiles, one workgroup each, under every plan)
                 if constexpr (CHAIN) af.bpg = (a.rows_per_group + P - 1) / P, af.nblocks = af.bpg * a.ngroups;
                 hipLaunchKernelGGL((rk45_finish_kernel<P, MODEL>), dim3(af.nblocks), blk, lds, st, af, *net, denoise_scale, do_denoise, x_out);
                 if (traj && nstates > 0)
@@ -921,7 +935,11 @@ static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *pro
     if (model < 0 || model > 2 || (model == 2 && !probe)) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
     // launch plan of the stage kernels (score_trunk.h: score_plan_rows): 16 / 32-row tiles or the 128-row chain form; plan != 0 forces one
-    int P = plan ? plan : (model == 0 ? score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k) : score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k));
+    if (plan == 0) plan = model == 0 ? score_plan_latency(ngroups * rg, ngroups > 1 ? rg : 0, k) : score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    if (plan < 0) return GP_EINVAL;
+    const int P = plan & ~GP_PLAN_HEADSPLIT;
+    a->hsplit = (plan & GP_PLAN_HEADSPLIT) ? 3 : 1;
+    if (a->hsplit == 3 && (model != 0 || P != 16)) return GP_EINVAL;  // one head per workgroup: score model, 16-row tiles
     if (P != 16 && P != 32 && P != 64 && P != 128) return GP_EINVAL;
     if (model != 0 && (P == 32 || P == 64)) return GP_EINVAL;  // forward + backward: 16-row tiles (score_bwd.h) or the 128-row chain form (trunk_chain_vjp.h)
     if (P == 128 && !gp_chain::Cfg<2>::fits(k)) return GP_EINVAL;
@@ -974,6 +992,9 @@ int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int 
     if (P == 128)
         return rk45_phase_impl<32, 0, true>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
                                             (hipStream_t)s);
+    if (a.hsplit == 3)
+        return rk45_phase_impl<16, 0, false, true>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                                   (hipStream_t)s);
     return P == 16 ? GP_RK45_CALL(16, 0) : (P == 64 ? GP_RK45_CALL(64, 0) : GP_RK45_CALL(32, 0));
 #undef GP_RK45_CALL
 }
@@ -982,14 +1003,21 @@ int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k) {
     if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || model < 0 || model > 2) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
     if (model != 0) return score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
-    return score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    return score_plan_latency(ngroups * rg, ngroups > 1 ? rg : 0, k);
 }
+
+int gp_plan_headsplit_pays(int ntiles16) { return headsplit_pays(ntiles16) ? 1 : 0; }
 
 int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec, float *tvec,
                           const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj, int traj_cap,
                           double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates, double *x_out,
                           gp_stream_t s) {
-    return gp_rk45_phase_model(0, 0, nullptr, phase, ngroups, nclouds_per_group, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap, t0,
+    // the entry points that predate the plan argument keep the partials size their contract states ([3][ngroups * ceil(rows per group /
+    // tile)]): whole tiles - the head-split plan (three partial sums per tile) is reached through gp_rk45_phase_model only
+    if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0) return GP_EINVAL;
+    const int rg = nclouds_per_group * k, legacy_plan = score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    if (legacy_plan < 0) return GP_EINVAL;
+    return gp_rk45_phase_model(0, legacy_plan, nullptr, phase, ngroups, nclouds_per_group, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap, t0,
                                t_bound, rtol, atol, denoise_scale, do_denoise, nstates, x_out, nullptr, 0, s);
 }
 
@@ -997,10 +1025,11 @@ int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nb
                          const gp_scorenet *net, const float *cvec, float *tvec, const float *centre, void *state, double *y, double *ynew,
                          double *K, double *partials, double *traj, int traj_cap, double t0, double t_bound, double rtol, double atol,
                          double denoise_scale, int do_denoise, int nstates, double *x_out, gp_stream_t s) {
-    if (ngroups <= 0 || nblocks <= 0 || !grp_info || !blk_info || (tile != 16 && tile != 32) || nclouds_total <= 0 || k <= 0 || !net || !cvec ||
-        !tvec || !centre || !state || !y || !ynew || !K || !partials)
+    if (ngroups <= 0 || nblocks <= 0 || !grp_info || !blk_info || (tile != 16 && tile != 32 && tile != (16 | GP_PLAN_HEADSPLIT)) || nclouds_total <= 0 ||
+        k <= 0 || !net || !cvec || !tvec || !centre || !state || !y || !ynew || !K || !partials)
         return GP_EINVAL;
     OdeArgs a;
+    a.hsplit = (tile & GP_PLAN_HEADSPLIT) ? 3 : 1;
     a.nrows = nclouds_total * k, a.kcand = k, a.nblocks = nblocks;
     a.ngroups = ngroups, a.bpg = 1, a.rows_per_group = 0;
     a.blk_info = blk_info, a.grp_info = grp_info;
@@ -1008,6 +1037,9 @@ int gp_rk45_phase_ragged(int phase, int ngroups, const int32_t *grp_info, int nb
     a.y = y, a.ynew = ynew, a.K = K, a.partials = partials, a.traj = traj, a.x32 = nullptr;
     a.probe = nullptr, a.ncomp = 9;
     a.ext_sums = nullptr, a.ext_rows = 0;
+    if (a.hsplit == 3)
+        return rk45_phase_impl<16, 0, false, true>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
+                                                   (hipStream_t)s);
     return tile == 16 ? rk45_phase_impl<16, 0>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,
                                                (hipStream_t)s)
                       : rk45_phase_impl<32, 0>(phase, a, net, traj, traj_cap, t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, centre, x_out,

@@ -199,9 +199,13 @@ struct TrunkNoEmit {};
 // rows >= nrows are clamped duplicates.
 // emit(h, chunk index, p-chunk, post-ReLU head activations f32x4, w_out rows of the head for these 4 channels, channel 0..767):
 // optional hook on every head-layer fragment (the backward seed of gp_score_div is built there).
-template <int P, bool KEEP_H1 = false, class Emit = TrunkNoEmit>
+// SPLIT (the latency regime's "head-split" plan, GP_PLAN_HEADSPLIT): the workgroup evaluates pose_encoder and ONE head, `hsel` - a tile is
+// served by three workgroups on three CUs, each streaming half the weights (0.5 MB instead of 1 MB) and issuing half the MFMAs; only
+// components 3 hsel .. 3 hsel + 2 of f_theta are produced (the others are left untouched in H1).  Same MFMA sequence per accumulator, same
+// combine order per component: the components a workgroup produces are bit-identical to the unsplit tile's.
+template <int P, bool KEEP_H1 = false, class Emit = TrunkNoEmit, bool SPLIT = false>
 __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net, const float *__restrict__ cvec, const float *__restrict__ tvec,
-                                             int row0, int nrows, int kcand, TrunkPre<P> &pre, Emit emit = Emit()) {
+                                             int row0, int nrows, int kcand, TrunkPre<P> &pre, Emit emit = Emit(), int hsel = 0) {
     using L = TrunkLds<P, KEEP_H1>;
     constexpr int PT = P / 16, NW = TrunkCfg<P>::NW, NV = TrunkCfg<P>::NV, NT = TrunkCfg<P>::NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -211,7 +215,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
 #pragma unroll
     for (int h = 0; h < 3; ++h)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) nch[h][i] = 16 * h + wave + NW * i;  // head h owns n-chunks [16h, 16h+16); first NV valid
+        for (int i = 0; i < 4; ++i) nch[h][i] = 16 * (SPLIT ? hsel : h) + wave + NW * i;  // head h owns n-chunks [16h, 16h+16); first NV valid
     int cloud[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
@@ -235,16 +239,17 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
     __syncthreads();
     // ---- stacked head layer (256 -> 768) with the 256 -> 3 output layers folded into the epilogue
 #pragma unroll
-    for (int h = 0; h < 3; ++h) {
+    for (int h = 0; h < (SPLIT ? 1 : 3); ++h) {
+        const int hh = SPLIT ? hsel : h;  // the head this iteration evaluates
         f32x4 acc[4][PT];
         // next head's first weight stages are requested before this head runs (hides the cold start)
-        if (h < 2) mfma_preload<NV>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
+        if (!SPLIT && h < 2) mfma_preload<NV>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
         mfma_run<NV, PT>(stH[h & 1], H2, L::LDH, 0, net.w_headx, HID / 16, HEADS / 16, nch[h], acc);
         float part[PT][3];  // [p-chunk][component], this wave's n-chunks of head h
 #pragma unroll
         for (int p = 0; p < PT; ++p) part[p][0] = part[p][1] = part[p][2] = 0.f;
         HeadOps<PT, NV> o;
-        head_ops_load<P, PT, NV, KEEP_H1>(o, lds, pre.staged, cvec, tvec, h, nch[h], cloud, pre.cloud0);
+        head_ops_load<P, PT, NV, KEEP_H1>(o, lds, pre.staged, cvec, tvec, hh, nch[h], cloud, pre.cloud0);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
 #pragma unroll
@@ -254,7 +259,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
                 v.y = fmaxf(v.y, 0.f);
                 v.z = fmaxf(v.z, 0.f);
                 v.w = fmaxf(v.w, 0.f);
-                if constexpr (!__is_same(Emit, TrunkNoEmit)) emit(h, i, p, v, o.w0[i], o.w1[i], o.w2[i], nch[h][i] * 16 + 4 * (lane >> 4));
+                if constexpr (!__is_same(Emit, TrunkNoEmit)) emit(hh, i, p, v, o.w0[i], o.w1[i], o.w2[i], nch[h][i] * 16 + 4 * (lane >> 4));
                 part[p][0] += v.x * o.w0[i].x + v.y * o.w0[i].y + v.z * o.w0[i].z + v.w * o.w0[i].w;
                 part[p][1] += v.x * o.w1[i].x + v.y * o.w1[i].y + v.z * o.w1[i].z + v.w * o.w1[i].w;
                 part[p][2] += v.x * o.w2[i].x + v.y * o.w2[i].y + v.z * o.w2[i].z + v.w * o.w2[i].w;
@@ -270,14 +275,14 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) red[(wave * P + p * 16 + lane) * 12 + 3 * h + c] = part[p][c];
+                    for (int c = 0; c < 3; ++c) red[(wave * P + p * 16 + lane) * 12 + 3 * hh + c] = part[p][c];
             }
         } else {
             // every lane parks its partial sums; the 4 channel groups x NW waves are combined below in a fixed order
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) red[((wave * 4 + (lane >> 4)) * P + p * 16 + (lane & 15)) * 12 + 3 * h + c] = part[p][c];
+                for (int c = 0; c < 3; ++c) red[((wave * 4 + (lane >> 4)) * P + p * 16 + (lane & 15)) * 12 + 3 * hh + c] = part[p][c];
         }
     }
     __syncthreads();
@@ -287,6 +292,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         const int e = tid + it * NT;
         if (e < P * POSE) {
             const int r = e / POSE, j = e - r * POSE;
+            if (SPLIT && j / 3 != hsel) continue;  // (uniform control flow is not needed below: the barrier follows the loop)
             float v = 0.f;
 #pragma unroll
             for (int q = 0; q < L::NRED; ++q) v += red[(q * P + r) * 12 + j];
@@ -348,6 +354,20 @@ static inline int score_plan_rows(int nrows, int rows_per_group, int kcand) {
     if (c64 < cb) best = 64, cb = c64;
     if (c128 < cb) best = 128, cb = c128;
     return cb < inf ? best : -1;
+}
+// The head-split plan (GP_PLAN_HEADSPLIT, round 5) for the LATENCY regime: a 16-row tile drags the whole 0.53 MFLOP / row network - and
+// 1 MB of weights - through ONE CU per evaluation while most of the chip idles (a tracking frame: 16-19 tiles, BASELINE configs[0]: one).
+// Three workgroups per tile, each recomputing pose_encoder (25 % of the FLOPs) and owning one head: half the weight stream and half the
+// MFMA issue per workgroup.  It pays while every workgroup still gets a CU of its own (tiles x 3 <= CUs); beyond that the recomputation
+// (1.5x the work) loses.  Measured: profiles/r5_plans.txt.
+static inline bool headsplit_pays(int ntiles16) { return ntiles16 * 3 <= gp_num_cus(); }
+// plan for score-model launches whose callers can run head-split (the RK45 driver, the PC step): score_plan_rows, upgraded to
+// 16 | GP_PLAN_HEADSPLIT in the latency regime
+static inline int score_plan_latency(int nrows, int rows_per_group, int kcand) {
+    const int p = score_plan_rows(nrows, rows_per_group, kcand);
+    if (p != 16) return p;
+    const int tiles = rows_per_group > 0 ? (nrows / rows_per_group) * ((rows_per_group + 15) / 16) : (nrows + 15) / 16;
+    return headsplit_pays(tiles) ? (16 | GP_PLAN_HEADSPLIT) : 16;
 }
 // The same choice for the forward + vector-Jacobian right-hand sides (energy model's score, likelihood ODE): 16-row tiles (score_bwd.h)
 // or the 128-row chain form (trunk_chain_vjp.h).  Measured on MI355X, K = 50, us per launch of the energy model's PC step

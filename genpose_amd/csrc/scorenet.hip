@@ -171,6 +171,10 @@ struct PcArgs {
     const float *gn_ext;             // [nsteps][ngroups] or null: the batch's gradient-norm statistic supplied from outside (a batch that is
     int ngroups;                     //   sharded over several GPUs, all-reduced between the launches): the SUM of |score| over all its
     float gn_rows;                   //   rows when gn_rows > 0 (= that row count), else the mean itself
+    // head-split plan (GP_PLAN_HEADSPLIT): workgroup 3 t + h evaluates head h of 16-row tile t and writes components 3 h .. 3 h + 2 of the
+    // score; a row's norm needs all nine, so the partial sums are per ROW AND HEAD - partials [nsteps][3 * rows], entry 3 r + h = the sum of
+    // squares of row r's three components of head h - and the next launch reduces sqrt(p[3r] + p[3r+1] + p[3r+2]) over its batch's rows.
+    // (nparts = 3 * nrows, ppg = 3 * rows_per_group; wgpg counts TILES per group.)
 };
 
 // Kernel for step i (0 <= i <= nsteps):
@@ -181,13 +185,17 @@ struct PcArgs {
 // MODEL 0: the score network (score = f / (sigma + 1e-7), scorenet.py:217).  MODEL 1: the ENERGY network, whose score is the
 // gradient of its inner-product energy (energynet.py:200-222): forward + vector-Jacobian product in the tile (score_bwd.h), 16-row
 // tiles only.  The same kernel otherwise: sampling from the energy model is the same captured launch chain.
-template <int P, int MODEL>
+// SPLIT: the head-split plan (see PcArgs): three workgroups per tile.  Each finishes step i-1 for all 16 rows (the update is row-local
+// and cheap; identical in the three, workgroup h = 0 stores) and evaluates ONE head of the score at t_i.
+template <int P, int MODEL, bool SPLIT = false>
 __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_scorenet net) {
     static_assert(MODEL == 0 || P == gp_bwd::DP, "the backward pass runs on 16-row tiles");
+    static_assert(!SPLIT || (MODEL == 0 && P == 16), "head-split: score model, 16-row tiles");
     using L = TrunkLds<P, MODEL == 1>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float s_gn;
-    const int row0 = blockIdx.x * P, tid = threadIdx.x, i = a.step;
+    const int tile = SPLIT ? blockIdx.x / 3 : blockIdx.x, hsel = SPLIT ? blockIdx.x - 3 * tile : 0;
+    const int row0 = tile * P, tid = threadIdx.x, i = a.step;
     TrunkPre<P> pre;
     float sigma = 1.f;
     if (i < a.nsteps) {
@@ -219,13 +227,17 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         constexpr int LASTW = TrunkCfg<P>::NT - 64;
         if (a.gn_ext) {
             if (tid == LASTW) {
-                const float v = a.gn_ext[(size_t)(i - 1) * a.ngroups + blockIdx.x / a.wgpg];
+                const float v = a.gn_ext[(size_t)(i - 1) * a.ngroups + tile / a.wgpg];
                 s_gn = a.gn_rows > 0.f ? v / a.gn_rows : v;
             }
         } else if (tid >= LASTW) {
             float s = 0.f;
-            const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)(blockIdx.x / a.wgpg) * a.ppg;
-            for (int q = tid - LASTW; q < a.ppg; q += 64) s += pp[q];
+            const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)(tile / a.wgpg) * a.ppg;
+            if constexpr (SPLIT) {
+                for (int r = tid - LASTW; r < a.rows_per_group; r += 64) s += sqrtf((pp[3 * r] + pp[3 * r + 1]) + pp[3 * r + 2]);
+            } else {
+                for (int q = tid - LASTW; q < a.ppg; q += 64) s += pp[q];
+            }
             s = wave_sum_f32(s);
             if (tid == LASTW) s_gn = s / (float)a.rows_per_group;
         }
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         if (tid < P) {
             float mx[9];
             pc_update_row(xv, gr, zz1, zz2, s_gn, g, dt, sqdt, mx);
-            if (live) {
+            if (live && hsel == 0) {
                 if (a.traj) {
                     float *tr = a.traj + ((size_t)(i - 1) * a.nrows + r) * 9;
 #pragma unroll
@@ -266,10 +278,11 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     float *F;
     int ldf;
     if constexpr (MODEL == 0) {
-        trunk_ftheta<P>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre);
+        trunk_ftheta<P, false, TrunkNoEmit, SPLIT>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre, TrunkNoEmit(), hsel);
         F = lds + L::OFF_H1, ldf = L::LDH;
         for (int e = tid; e < P * POSE; e += TrunkCfg<P>::NT) {
             const int r = e / POSE, j = e - r * POSE;
+            if (SPLIT && j / 3 != hsel) continue;
             const float v = F[r * ldf + j] / (sigma + 1e-7f);
             F[r * ldf + j] = v;
             if (row0 + r < a.nrows) a.score[(size_t)(row0 + r) * POSE + j] = v;
@@ -283,6 +296,14 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         }
     }
     __syncthreads();
+    if constexpr (SPLIT) {
+        // per row: the sum of squares of this head's three components (the row's norm is put together by the next launch)
+        if (tid < P && row0 + tid < a.nrows) {
+            const float *f = F + tid * ldf + 3 * hsel;
+            a.partials[(size_t)i * a.nparts + 3 * (size_t)(row0 + tid) + hsel] = (f[0] * f[0] + f[1] * f[1]) + f[2] * f[2];
+        }
+        return;
+    }
     if (tid < 64) {
         float s = 0.f;
         for (int r = tid; r < P; r += 64) {
@@ -557,7 +578,13 @@ int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k,
         if (P == 0) P = score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
         if (P != 16 && P != 128) return GP_EINVAL;
     }
-    if (P == 0) P = score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    if (P == 0) P = score_plan_latency(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    if (P == (16 | GP_PLAN_HEADSPLIT)) {  // three workgroups per 16-row tile, one head each: one partial per row and head (PcArgs)
+        if (model != 0 || (ngroups > 1 && rg % 16 != 0)) return GP_EINVAL;
+        *tile_out = P;
+        *nparts_out = 3 * ngroups * rg;
+        return GP_OK;
+    }
     if (P != 16 && P != 32 && P != 64 && P != 128) return GP_EINVAL;
     if (P == 128 && !gp_chain::Cfg<2>::fits(k)) return GP_EINVAL;
     if (ngroups > 1 && rg % pc_rows_per_wg(P) != 0) return GP_EINVAL;  // a workgroup must not straddle two batches
@@ -579,6 +606,11 @@ int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int
     const int rc = gp_pc_layout(model, tile, ngroups, nclouds_per_group, k, &P, &nparts);
     if (rc != GP_OK) return rc;
     if (model == 1 && (!net->w_headx_t || !net->w_pose2_t || !net->w_pose0_t)) return GP_EINVAL;
+    const bool split = P == (16 | GP_PLAN_HEADSPLIT);
+    if (split) {
+        if (gn_ext) return GP_EINVAL;  // a sharded batch's callers sum whole-tile partials between the launches: tile plans only
+        P = 16;
+    }
     PcArgs a;
     a.nrows = R, a.kcand = k, a.step = step, a.nsteps = nsteps;
     a.nparts = nparts, a.ppg = nparts / ngroups, a.rows_per_group = rg;
@@ -591,7 +623,8 @@ int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int
     if (P == 128) return model == 1 ? launch_pc_chain<2, 1>(a, net, nwg, st) : launch_pc_chain<2, 0>(a, net, nwg, st);
     static bool attr_done = false;
     if (!attr_done) {
-        if (set_lds(pc_step_kernel<16, 0>, trunk_lds_bytes<16>()) || set_lds(pc_step_kernel<32, 0>, trunk_lds_bytes<32>()) ||
+        if (set_lds(pc_step_kernel<16, 0>, trunk_lds_bytes<16>()) || set_lds(pc_step_kernel<16, 0, true>, trunk_lds_bytes<16>()) ||
+            set_lds(pc_step_kernel<32, 0>, trunk_lds_bytes<32>()) ||
             set_lds(pc_step_kernel<64, 0>, trunk_lds_bytes<64>()) ||
             set_lds(pc_step_kernel<16, 1>, gp_bwd::LDS_BYTES))
             return GP_ELAUNCH;
@@ -599,6 +632,8 @@ int gp_pc_step_plan(int model, int tile, int ngroups, int nclouds_per_group, int
     }
     if (model == 1)
         hipLaunchKernelGGL((pc_step_kernel<16, 1>), dim3(nwg), dim3(TrunkCfg<16>::NT), gp_bwd::LDS_BYTES, st, a, *net);
+    else if (split)
+        hipLaunchKernelGGL((pc_step_kernel<16, 0, true>), dim3(3 * nwg), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), st, a, *net);
     else if (P == 16)
         hipLaunchKernelGGL((pc_step_kernel<16, 0>), dim3(nwg), dim3(TrunkCfg<16>::NT), trunk_lds_bytes<16>(), st, a, *net);
     else if (P == 64)

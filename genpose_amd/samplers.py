@@ -53,8 +53,16 @@ class PCSampler:
         if _lib.lib().gp_pc_layout(self.model, int(tile), groups, B // groups, K, ctypes.byref(t_out), ctypes.byref(n_out)) != 0:
             raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                              "run the batches separately")
-        self.tile, self.nparts = t_out.value, n_out.value
-        self.kernel_name = (f"pc_step_kernel<{self.tile}>" if self.model == 0 else f"pc_step_kernel<{self.tile},energy>") if self.tile in (16, 32, 64) else \
+        if coupling_group is not None and (t_out.value & _lib.PLAN_HEADSPLIT):
+            # a sharded batch: the per-step sums below run over whole-tile partials - the plain 16-row tiles, not the head-split plan
+            if _lib.lib().gp_pc_layout(self.model, 16, groups, B // groups, K, ctypes.byref(t_out), ctypes.byref(n_out)) != 0:
+                raise ValueError("16-row tiles do not fit this batch")
+        # self.plan is what the launches are given; self.tile the rows per workgroup of it; self.hsplit = 3 under the head-split plan of
+        # the latency regime (three workgroups per 16-row tile, one head of the network each - GP_PLAN_HEADSPLIT)
+        self.plan, self.nparts = t_out.value, n_out.value
+        self.tile, self.hsplit = self.plan & ~_lib.PLAN_HEADSPLIT, (3 if self.plan & _lib.PLAN_HEADSPLIT else 1)
+        self.kernel_name = ("pc_step_kernel<16,0,split>" if self.hsplit == 3 else f"pc_step_kernel<{self.tile}>" if self.model == 0
+                            else f"pc_step_kernel<{self.tile},energy>") if self.tile in (16, 32, 64) else \
             ("pc_step_chain_kernel<2>" if self.model == 0 else "pc_step_chain_kernel<2,energy>")
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)
@@ -79,7 +87,7 @@ class PCSampler:
 
     def launch_step(self, i):
         """Launch i of the chain (0 <= i <= n) on the current stream: finishes step i-1 and, for i < n, evaluates the score at t_i."""
-        _lib.call("gp_pc_step_plan", self.model, self.tile, self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
+        _lib.call("gp_pc_step_plan", self.model, self.plan, self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
                   ptr(self.sched), ptr(self.z1), ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
                   ptr(self.traj), ptr(self.gn_ext), self.gn_rows, stream_ptr())
 
@@ -180,8 +188,16 @@ class ODESampler:
             # boundary (gp_rk45_phase_ragged).  B and len(group_clouds) are CAPACITIES: set_groups() re-fills the device tables for
             # any grouping that fits, so the captured graphs (fixed grids) serve frames whose object counts change.
             groups = len(group_clouds)
-            self.tile = _lib.lib().gp_score_tile_rows(B * K)  # 16 rows, or 32 once the launch is big enough to be MFMA-bound
+            self.tile = (int(tile) & ~_lib.PLAN_HEADSPLIT) if tile else _lib.lib().gp_score_tile_rows(B * K)  # 16 rows, or 32 once the launch is MFMA-bound
+            if self.tile not in (16, 32):
+                raise ValueError("ragged groups run on 16- or 32-row tiles")
             self.nblocks = (B * K + self.tile - 1) // self.tile + groups  # every group wastes less than one tile
+            # latency regime (one sequence's frames: a few dozen tiles at capacity): three workgroups per tile, one head of the network each
+            if tile:
+                self.hsplit = 3 if int(tile) & _lib.PLAN_HEADSPLIT else 1
+            else:
+                self.hsplit = 3 if self.tile == 16 and _lib.lib().gp_plan_headsplit_pays(self.nblocks) else 1
+            self.plan = self.tile | (_lib.PLAN_HEADSPLIT if self.hsplit == 3 else 0)
             self.blk_info = torch.zeros(self.nblocks, 3, dtype=torch.int32, device=self.dev)
             self.grp_info = torch.zeros(groups, 4, dtype=torch.int32, device=self.dev)
             self._tables_host = (torch.zeros(self.nblocks, 3, dtype=torch.int32).pin_memory(), torch.zeros(groups, 4, dtype=torch.int32).pin_memory())
@@ -191,8 +207,10 @@ class ODESampler:
         R = self.R = B * K
         if not self.ragged:
             # forward + backward right-hand sides (energy model, likelihood): 16-row tiles or, for large launches, the 128-row chain form
-            self.tile = int(tile) if tile else _lib.lib().gp_rk45_plan_rows(self.model, groups, B // groups, K)
-            if self.tile not in (16, 32, 64, 128) or (self.model != 0 and self.tile in (32, 64)) or (groups > 1 and (R // groups) % self.tile):
+            self.plan = int(tile) if tile else _lib.lib().gp_rk45_plan_rows(self.model, groups, B // groups, K)
+            # plan = rows per workgroup (| GP_PLAN_HEADSPLIT: three workgroups per 16-row tile, one head each - the latency regime)
+            self.tile, self.hsplit = self.plan & ~_lib.PLAN_HEADSPLIT, (3 if self.plan & _lib.PLAN_HEADSPLIT else 1)
+            if (self.hsplit == 3 and (self.tile != 16 or self.model != 0)) or self.tile not in (16, 32, 64, 128) or (self.model != 0 and self.tile in (32, 64)) or (groups > 1 and (R // groups) % self.tile):
                 raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                                  "run the batches separately")
             self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
@@ -204,7 +222,7 @@ class ODESampler:
         d = lambda *s: torch.zeros(*s, dtype=torch.float64, device=self.dev)
         nc = self.ncomp
         self.y, self.ynew, self.Kbuf = d(R * nc), d(R * nc), d(7, R * nc)
-        self.partials = d(3, self.nblocks)
+        self.partials = d(3, self.nblocks * self.hsplit)
         self.x_out = d(R, nc)
         self.probe = torch.zeros(R, 9, device=self.dev) if self.model == 2 else None
         self.coupling_group, self.ext_sums, self.ext_rows = coupling_group, None, 0
@@ -266,15 +284,15 @@ class ODESampler:
                 ptr(traj), 0 if traj is None else traj.shape[0], cd(t0), cd(t_bound), cd(rtol), cd(atol), cd(dscale), do_denoise, nstates,
                 ptr(self.x_out), stream_ptr())
         if self.ragged:
-            _lib.call("gp_rk45_phase_ragged", phase, self.groups, ptr(self.grp_info), self.nblocks, ptr(self.blk_info), self.tile, self.B, self.K,
+            _lib.call("gp_rk45_phase_ragged", phase, self.groups, ptr(self.grp_info), self.nblocks, ptr(self.blk_info), self.plan, self.B, self.K,
                       self.net.w.ref(), *tail)
         else:
-            _lib.call("gp_rk45_phase_model", self.model, self.tile, ptr(self.probe), phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail[:-1],
+            _lib.call("gp_rk45_phase_model", self.model, self.plan, ptr(self.probe), phase, self.groups, self.B // self.groups, self.K, self.net.w.ref(), *tail[:-1],
                       ptr(self.ext_sums), self.ext_rows, tail[-1])
             if self.ext_sums is not None and phase in (1, 2, 3):
                 # sharded batch: the controller decides on the sums of squares over ALL shards
                 self._dist.all_reduce(self.ext_sums, op=self._dist.ReduceOp.SUM, group=self.coupling_group)
-                _lib.call("gp_rk45_phase_model", self.model, self.tile, ptr(self.probe), phase + 10, self.groups, self.B // self.groups, self.K, self.net.w.ref(),
+                _lib.call("gp_rk45_phase_model", self.model, self.plan, ptr(self.probe), phase + 10, self.groups, self.B // self.groups, self.K, self.net.w.ref(),
                           *tail[:-1], ptr(self.ext_sums), self.ext_rows, tail[-1])
 
     def _attempt(self, traj):

@@ -265,7 +265,10 @@ int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int 
 /* Launch plan of the PC sampler for (ngroups x nclouds_per_group clouds x k candidates) and a model (see gp_pc_step_plan): tile = 0 asks for the automatic choice, else
  * 16 / 32 / 64 / 128 as in gp_score_eval_plan.  *tile_out = the plan taken, *nparts_out = partial sums of |score| per step
  * (`partials` must hold nsteps * nparts floats: one per workgroup in the tile form, one per wave in the chain form).  GP_EINVAL when a
- * workgroup of the plan would straddle two groups. */
+ * workgroup of the plan would straddle two groups.  In the latency regime (score model, tiles x 3 <= CUs) the automatic choice is
+ * 16 | GP_PLAN_HEADSPLIT (defined with the RK45 driver below): three workgroups per 16-row tile, one head of the network each; its
+ * partials are per row and head (nparts = 3 x rows: sums of squares of a head's three score components, put together by the next
+ * launch), and it refuses gn_ext (a sharded batch's caller sums per-tile partials: force tile = 16 there). */
 int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out);
 /* gp_pc_step_coupled with the plan chosen by the caller (tile as above; 0 = automatic; every launch of one chain must use the same
  * plan) and the MODEL whose score drives the sampler: 0 = the score network (f / (sigma + 1e-7), scorenet.py:217); 1 = the ENERGY
@@ -340,8 +343,14 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
  * controller on the reduced sums (+ trajectory record).  Every shard then takes the accept / reject sequence of the unsharded batch.
  * ext_sums = NULL: the controller reduces the local partials itself (phases 11-13 are GP_EINVAL).
  * plan: rows per workgroup of the stage kernels - 16 / 32 / 64 = tile form (models 1 and 2, which need the backward pass: 16 only), 128 = the
- * chain form of the trunk (every model; k >= 43, rows_per_group % 128 == 0 when ngroups > 1); 0 = gp_rk45_plan_rows() picks.
- * partials [3][ngroups * ceil(rows_per_group / plan)]. */
+ * chain form of the trunk (every model; k >= 43, rows_per_group % 128 == 0 when ngroups > 1); 16 | GP_PLAN_HEADSPLIT = the latency
+ * regime's head-split plan (score model): THREE workgroups per 16-row tile, each recomputing pose_encoder and evaluating one head
+ * (scorenet.py:178-222: the three fusion tails are independent given the pose features) - half the weight stream and half the MFMA issue
+ * per workgroup, 3x the CUs; every stage of an attempt is then a launch of its own (a stage reads all nine components of the previous
+ * one); picked by gp_rk45_plan_rows() while tiles x 3 <= CUs (gp_plan_headsplit_pays).  0 = gp_rk45_plan_rows() picks.
+ * partials [3][ngroups * ceil(rows_per_group / rows per workgroup) * (3 under the head-split plan)]. */
+#define GP_PLAN_HEADSPLIT 0x100
+int gp_plan_headsplit_pays(int ntiles16); /* 1 while three workgroups per 16-row tile still get a CU each */
 int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k);
 int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,

@@ -115,6 +115,7 @@ def test_duplicate_model_names_follow_list_index():
         assert torch.equal(r1["init_x"], want_x), use_graphs
         assert not torch.equal(prev[0], prev[1])  # (the two mugs did end up at different poses: the rule is visible)
     # the multi-sequence tracker: same rule, and the one-tensor path only for unique names
+    sa.net.prior_fn = lambda shape, T=1.0: torch.randn(shape, generator=gen) * 0.04
     multi = MultiSequenceTracker(sa, ea, 2, repeat_num=K, T0=0.15)
     frames = lambda f: [((base + 0.002 * f).cuda(), names, gt), ((base[:2] + 0.002 * f).cuda(), ["can", "laptop"], gt[:2])]
     m0 = multi.step(frames(0))
