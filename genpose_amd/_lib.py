@@ -50,6 +50,7 @@ SIGNATURES = {
     "gp_sa_pre_mlp_max": [c_int] * 7 + [P, P, P, P, c_int, c_int] + [P] * 7 + [c_int, c_int, P],
     "gp_sa_pre_mlp_max_layout": [c_int] * 8 + [P, P, P, P, c_int, c_int] + [P] * 7 + [c_int, c_int, P],
     "gp_sa_tail_position": [c_int, c_int],
+    "gp_sa_pre_mlp_max_bf16x3": [c_int] * 7 + [P, P, P, P, c_int, c_int] + [P] * 7 + [c_int, c_int, P],
     "gp_pack_weight_size": [c_int, c_int],
     "gp_pack_weight": [c_int, c_int, P, c_int, P],
     "gp_score_tile_rows": [c_int],

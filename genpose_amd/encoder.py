@@ -37,9 +37,15 @@ def _unpin_entry(key, ent):
 
 
 class Pointnet2EncoderHIP:
-    def __init__(self, state_dict, device="cuda", params="light", prefix="pts_encoder.", arith=None):
+    def __init__(self, state_dict, device="cuda", params="light", prefix="pts_encoder.", arith=None, precision="f32"):
         """arith: contraction convention of the squared distances in furthest point sampling and the ball queries ('A' | 'B' | 'C',
-        config.DEFAULT_DIST_ARITH when None; include/genpose_hip.h GP_ARITH_*)."""
+        config.DEFAULT_DIST_ARITH when None; include/genpose_hip.h GP_ARITH_*).
+        precision: 'f32' (default: every dense layer on the fp32 matrix pipe - what all parity claims and the headline bench line run) or
+        'bf16x3' (OPT-IN, exploratory, round 5): the 128-196-256 grouping level on the bf16 matrix pipe as three-term split products with
+        fp32 accumulation (csrc/sa_bf16x3.hip; ~2^-17 relative per product); centres and neighbourhoods are unaffected."""
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError(f"encoder precision {precision!r}: 'f32' or 'bf16x3'")
+        self.precision = precision
         self.device = torch.device(device)
         self.arith = dist_arith_code(arith)
         self.w = EncoderWeights(state_dict, self.device, params, prefix)
@@ -325,6 +331,14 @@ class Pointnet2EncoderHIP:
             off, zoff = 0, 0
             for i, sc in enumerate(scales):
                 (w1, b1), (w2, b2), (w3, b3) = sc.layers
+                if (self.precision == "bf16x3" and z is not None and sc.couts == [128, 196, 256] and nss[i] in (16, 32)
+                        and (B * npnt * nss[i]) % 32 == 0):
+                    w2s, b2s, w3s, b3s = sc.bf16x3_packs()
+                    _lib.call("gp_sa_pre_mlp_max_bf16x3", B, n, npnt, nss[i], 128, 196, 256, ptr(xyz), ptr(new_xyz), ptr(src["bq"][k][i]), ptr(z),
+                              zstride, zoff, ptr(sc.wxyz), ptr(b1), ptr(w2s), ptr(b2s), ptr(w3s), ptr(b3s), ptr(out), cout_total, off, st)
+                    off += sc.couts[2]
+                    zoff += sc.couts[0]
+                    continue
                 _lib.call("gp_sa_pre_mlp_max_layout", sc.hidden_layout, B, n, npnt, nss[i], sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(new_xyz),
                           ptr(src["bq"][k][i]), ptr(z), zstride, zoff, ptr(sc.wxyz), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out),
                           cout_total, off, st)

@@ -49,7 +49,8 @@ class GFObjectPose:
     def load_state_dict(self, state_dict, strict=True):
         sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
         params = getattr(self.cfg, "pointnet2_params", "light")
-        self.pts_encoder = Pointnet2EncoderHIP(sd, self.device, params, arith=getattr(self.cfg, "dist_arith", None))
+        self.pts_encoder = Pointnet2EncoderHIP(sd, self.device, params, arith=getattr(self.cfg, "dist_arith", None),
+                                               precision=getattr(self.cfg, "encoder_precision", "f32"))
         self.pose_score_net = ScoreNetHIP(sd, self.device)
         self._samplers.clear()
         return self

@@ -84,6 +84,9 @@ class SAScale:
             l += 1
         if l != 3:
             raise ValueError(f"{prefix}: the fused SA kernel expects 3-layer shared MLPs, found {l}")
+        self._folded_plain = [(W.clone(), b.clone()) for W, b in folded]  # channel order as trained (the fp32 packs below may permute it)
+        self._device = device
+        self._bf16x3 = None
         c2 = self.couts[1]
         if c2 % 16:
             # hidden width not a multiple of 16 (light level 2: 196): the channels of the last, partly filled 16-channel block go to
@@ -98,6 +101,51 @@ class SAScale:
             W3s[:, pos] = W3
             folded[1], folded[2] = (W2s, b2s), (W3s, b3)
         self.layers = [(pack_weight(W).to(device), pad_bias(b).to(device)) for W, b in folded]
+
+
+    def bf16x3_packs(self):
+        """Operands of the opt-in split-bf16 kernel (csrc/sa_bf16x3.hip) for layers 2 and 3: every weight as hi = bf16(w) and
+        lo = bf16(w - hi), in the fragment order of v_mfma_f32_16x16x32_bf16 with the k order the register chain produces -
+        k-block m = channels 32 m .. 32 m + 31, lane group g holds [32m + 4g .. +3] and [32m + 16 + 4g .. +3].
+        -> (w2 [KB1][NC2][2][64][8], b2 [32 KB2], w3 [2][KB2][8][2][64][8], b3) as int16 / float32 device tensors."""
+        if self._bf16x3 is None:
+            (_, _), (W2, b2), (W3, b3) = self._folded_plain
+            c1, c2, c3 = self.couts
+            nc2 = (c2 + 15) // 16
+            kb2 = (nc2 + 1) // 2
+            w2 = pack_bf16x3(W2, nc2, c1 // 32)                                   # [KB1][NC2][2][64][8]
+            w3 = pack_bf16x3(W3, c3 // 16, kb2)                                   # [KB2][16][2][64][8]
+            w3 = torch.stack([w3[:, :8], w3[:, 8:]], dim=0).contiguous()          # [half][KB2][8][2][64][8]: ring slice = (half, k-block)
+            b2p = torch.zeros(32 * kb2)
+            b2p[:c2] = b2
+            dev = self._device
+            self._bf16x3 = (w2.to(dev), b2p.to(dev), w3.to(dev), b3.float().contiguous().to(dev))
+        return self._bf16x3
+
+
+def pack_bf16x3(W, n_chunks, k_blocks):
+    """W [n_out, k_in] f32 -> int16 [k_blocks][n_chunks][2 = hi, lo][64 lanes][8]: the A / B operand fragments of
+    v_mfma_f32_16x16x32_bf16 for output chunk nc (16 outputs) and k-block kb (32 inputs), lane l = (n = l % 16, g = l // 16), element e:
+    input channel 32 kb + (4 g + e if e < 4 else 16 + 4 g + e - 4) - two consecutive D fragments of the previous layer, as the register
+    chain of csrc/sa_bf16x3.hip holds them.  Out-of-range outputs / inputs are zero."""
+    W = W.detach().float().cpu()
+    n_out, k_in = W.shape
+    Wp = torch.zeros(16 * n_chunks, 32 * k_blocks)
+    Wp[:n_out, :k_in] = W
+    hi = Wp.to(torch.bfloat16)
+    lo = (Wp - hi.float()).to(torch.bfloat16)
+    lanes = torch.arange(64)
+    n, g = lanes % 16, lanes // 16
+    e = torch.arange(8)
+    koff = torch.where(e < 4, 4 * g[:, None] + e[None, :], 16 + 4 * g[:, None] + (e[None, :] - 4))  # [64, 8]
+    out = torch.empty(k_blocks, n_chunks, 2, 64, 8, dtype=torch.int16)
+    for kb in range(k_blocks):
+        for nc in range(n_chunks):
+            rows = (16 * nc + n)[:, None].expand(64, 8)
+            cols = 32 * kb + koff
+            out[kb, nc, 0] = hi[rows, cols].view(torch.int16)
+            out[kb, nc, 1] = lo[rows, cols].view(torch.int16)
+    return out.contiguous()
 
 
 class EncoderWeights:

@@ -166,6 +166,17 @@ int gp_sa_pre_mlp_max_layout(int hidden_layout, int b, int n, int np, int ns, in
                              const float *bias2, const float *wpack3, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s);
 int gp_sa_tail_position(int c2, int channel);
 
+/* OPT-IN, EXPLORATORY (round 5; csrc/sa_bf16x3.hip): gp_sa_pre_mlp_max for the level-2 shapes of the light encoder (c1, c2, c3 = 128, 196, 256;
+ * ns = 16 | 32; hoisted first layer: z required) with layers 2 and 3 on the BF16 matrix pipe as three-term split products
+ * (a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo, fp32 accumulate; relative error ~2^-17 per product instead of 2^-24).  w2_split / w3_split: the
+ * weights as hi / lo bf16 pairs in the fragment order of v_mfma_f32_16x16x32_bf16 (genpose_amd/weights.py: pack_bf16x3 -
+ * [c1/32][13][2][64][8] and [2][7][8][2][64][8] bf16); bias2 [224] zero padded, channel order as trained.  Never the default: the fp32 entry
+ * points above are what every parity claim and the headline bench line run.  b * np * ns must be a multiple of 32. */
+int gp_sa_pre_mlp_max_bf16x3(int b, int n, int np, int ns, int c1, int c2, int c3, const float *xyz, const float *new_xyz, const int32_t *idx,
+                             const float *z, int zstride, int zoff, const float *wxyz, const float *bias1, const void *w2_split, const float *bias2,
+                             const void *w3_split, const float *bias3, float *out, int cout_total, int cout_off, gp_stream_t s);
+
+
 /* Weight packing for the MFMA layers (host-callable helpers operating on HOST memory):
  * W is [n_out, k_in] row-major (torch Linear / 1x1 conv layout).  Packed size in floats = gp_pack_weight_size(). */
 int64_t gp_pack_weight_size(int n_out, int k_in);
