@@ -15,7 +15,8 @@
 //   * the D fragment of a layer (lane = point, four consecutive channels of a 16-channel chunk) still IS the next layer's operand: two chunks
 //     (2m, 2m+1) make the eight k-values a lane holds for k-block m of v_mfma_f32_16x16x32_bf16 - the host packs the weights in that k order
 //     (weights.py: pack_bf16x3);
-//   * layer 3 in two halves of eight output chunks (64 accumulator registers for the two sub-chunks), ring slice = (half, k-block) = 16 KB.
+//   * layer 3 in halves of eight output chunks (64 accumulator registers for the two sub-chunks), ring slice = (half, k-block) = 16 KB;
+//   * level 1 (64-64/96-128: all weights fit LDS) runs the same kernel without the ring and without a barrier in the loop.
 #include "gp_common.h"
 
 namespace {
@@ -51,17 +52,19 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8 &hi,
 
 __device__ __forceinline__ f32x4 relu4(const f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
 
-template <int C1, int C2, int C3, int NS>
-__global__ __launch_bounds__(512) void sa_chain_ring_bf16x3_kernel(SABfArgs a, int nunits_total) {
-    constexpr int Q1 = C1 / 16, KB1 = C1 / 32, NC2 = (C2 + 15) / 16, KB2 = (NC2 + 1) / 2, NC3H = 8, NWV = 8, NTH = 512;
-    static_assert(C1 % 32 == 0 && C3 == 256 && (NS == 16 || NS == 32), "level-2 shapes of the light / dense / lighter encoders");
-    constexpr int SLICE = NC3H * 2 * 64;   // bf16x8 (16 B) per ring slice: one (half, k-block) of layer 3
+// RING: layer-3 weights through the 3-slot ring (level 2: 224 KB of them); !RING: they are LDS-resident too and the loop has no barrier
+// (level 1: 64-64/96-128, 32-48 KB) - sa_chain_lds_kernel's form.
+template <int C1, int C2, int C3, int NS, bool RING>
+__global__ __launch_bounds__(512) void sa_chain_bf16x3_kernel(SABfArgs a, int nunits_total) {
+    constexpr int KB1 = C1 / 32, NC2 = (C2 + 15) / 16, KB2 = (NC2 + 1) / 2, NC3H = 8, NHALF = C3 / 128, NWV = 8, NTH = 512;
+    static_assert(C1 % 32 == 0 && C3 % 128 == 0 && (NS == 16 || NS == 32), "grouping levels 1 and 2 of the light / dense / lighter encoders");
+    constexpr int SLICE = NC3H * 2 * 64;   // bf16x8 (16 B) per slice: one (half, k-block) of layer 3 = 16 KB
     constexpr int PER_T = SLICE / NTH;
-    constexpr int NSL = 2 * KB2;           // slices per iteration
+    constexpr int NSL = NHALF * KB2;       // slices per iteration
     extern __shared__ __attribute__((aligned(16))) float lds[];
     bf16x8 *w2l = reinterpret_cast<bf16x8 *>(lds);                 // [KB1][NC2][2][64] resident
-    bf16x8 *ring = w2l + KB1 * NC2 * 2 * 64;                        // [3][SLICE]
-    f32x4 *w1l = reinterpret_cast<f32x4 *>(ring + 3 * SLICE);       // [C1] rows (wx, wy, wz, b1)
+    bf16x8 *ring = w2l + KB1 * NC2 * 2 * 64;                        // RING: [3][SLICE]; else all [NSL][SLICE] slices
+    f32x4 *w1l = reinterpret_cast<f32x4 *>(ring + (RING ? 3 : NSL) * SLICE);  // [C1] rows (wx, wy, wz, b1)
     float *b2l = reinterpret_cast<float *>(w1l + C1);               // [32 KB2]
     float *b3l = b2l + 32 * KB2;                                    // [C3]
     const int tid = threadIdx.x, lane = tid & 63, pt = lane & 15, g = lane >> 4;
@@ -75,16 +78,21 @@ __global__ __launch_bounds__(512) void sa_chain_ring_bf16x3_kernel(SABfArgs a, i
     for (int e = tid; e < C3; e += NTH) b3l[e] = a.b3[e];
     // ring prologue: slices 0 and 1 into slots 0 and 1; slice 2 held in registers
     bf16x8 hold[PER_T];
+    if constexpr (RING) {
 #pragma unroll
-    for (int u = 0; u < PER_T; ++u) {
-        ring[0 * SLICE + tid + u * NTH] = a.w3[0 * SLICE + tid + u * NTH];
-        ring[1 * SLICE + tid + u * NTH] = a.w3[1 * SLICE + tid + u * NTH];
-        hold[u] = a.w3[2 * SLICE + tid + u * NTH];
+        for (int u = 0; u < PER_T; ++u) {
+            ring[0 * SLICE + tid + u * NTH] = a.w3[0 * SLICE + tid + u * NTH];
+            ring[1 * SLICE + tid + u * NTH] = a.w3[1 * SLICE + tid + u * NTH];
+            hold[u] = a.w3[2 * SLICE + tid + u * NTH];
+        }
+    } else {
+        for (int e = tid; e < NSL * SLICE; e += NTH) ring[e] = a.w3[e];
     }
     __syncthreads();
     const int wave_global = blockIdx.x * NWV + (tid >> 6), nwaves = gridDim.x * NWV;
     const int my_units = wave_global < nunits_total ? (nunits_total - wave_global + nwaves - 1) / nwaves : 0;
-    const int nits_wg = (nunits_total + nwaves - 1) / nwaves;  // uniform over the grid: barrier counts match
+    // RING: every wave runs the same number of iterations (idle ones compute on clamped rows and store nothing): barrier counts match
+    const int nits_wg = RING ? (nunits_total + nwaves - 1) / nwaves : my_units;
     // unit `it` of this wave: 32 consecutive (centre, sample) rows = sub-chunks s = 0, 1 of 16 rows
     auto unit_of = [&](int it) { return it < my_units ? wave_global + it * nwaves : 0; };
     auto load_idx = [&](int it, int (&j)[2]) {
@@ -205,14 +213,14 @@ __global__ __launch_bounds__(512) void sa_chain_ring_bf16x3_kernel(SABfArgs a, i
             }
         // ---- layer 3 (transposed: lane = channel, registers x lane groups = the 16 points of a sub-chunk), eight output chunks at a time
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NHALF; ++half) {
             f32x4 acc3[NC3H][2];
 #pragma unroll
             for (int n = 0; n < NC3H; ++n) acc3[n][0] = acc3[n][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < KB2; ++kb) {
                 // slice gstep + 2 (held in registers since the previous step) -> its slot, last read in step gstep - 1
-                {
+                if constexpr (RING) {
                     bf16x8 *dst = ring + ((gstep + 2) % 3) * SLICE;
 #pragma unroll
                     for (int u = 0; u < PER_T; ++u) dst[tid + u * NTH] = hold[u];
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(512) void sa_chain_ring_bf16x3_kernel(SABfArgs a, i
 #pragma unroll
                     for (int u = 0; u < PER_T; ++u) hold[u] = src[tid + u * NTH];
                 }
-                const bf16x8 *slot = ring + (gstep % 3) * SLICE;
+                const bf16x8 *slot = RING ? ring + (gstep % 3) * SLICE : ring + (half * KB2 + kb) * SLICE;
 #pragma unroll
                 for (int n0 = 0; n0 < NC3H; n0 += 2) {
                     bf16x8 wh[2], wl[2];
@@ -242,8 +250,10 @@ __global__ __launch_bounds__(512) void sa_chain_ring_bf16x3_kernel(SABfArgs a, i
 #pragma unroll
                         for (int s = 0; s < 2; ++s) acc3[n0 + u][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h2hi[kb][s], wl[u], acc3[n0 + u][s], 0, 0, 0);
                 }
-                ++gstep;
-                __syncthreads();
+                if constexpr (RING) {
+                    ++gstep;
+                    __syncthreads();
+                }
             }
             // pooling over the points (max_i relu(x_i + b) = relu(max_i x_i + b): bias and ReLU once per channel, after the pooling)
 #pragma unroll
@@ -264,12 +274,12 @@ __global__ __launch_bounds__(512) void sa_chain_ring_bf16x3_kernel(SABfArgs a, i
     }
 }
 
-template <int C1, int C2, int C3, int NS>
+template <int C1, int C2, int C3, int NS, bool RING>
 int launch_bf16x3(const SABfArgs &a, int b, hipStream_t st) {
-    constexpr int KB1 = C1 / 32, NC2 = (C2 + 15) / 16, KB2 = (NC2 + 1) / 2;
-    const size_t lds = ((size_t)KB1 * NC2 * 2 * 64 + 3 * 8 * 2 * 64 + C1) * 16 + (size_t)(32 * KB2 + C3) * sizeof(float);
+    constexpr int KB1 = C1 / 32, NC2 = (C2 + 15) / 16, KB2 = (NC2 + 1) / 2, NSL = (C3 / 128) * KB2;
+    const size_t lds = ((size_t)KB1 * NC2 * 2 * 64 + (RING ? 3 : NSL) * 8 * 2 * 64 + C1) * 16 + (size_t)(32 * KB2 + C3) * sizeof(float);
     if (lds > 160 * 1024) return GP_EINVAL;
-    auto kern = sa_chain_ring_bf16x3_kernel<C1, C2, C3, NS>;
+    auto kern = sa_chain_bf16x3_kernel<C1, C2, C3, NS, RING>;
     static bool done = false;
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GP_ELAUNCH;
@@ -277,7 +287,8 @@ int launch_bf16x3(const SABfArgs &a, int b, hipStream_t st) {
     }
     const int nunits = (int)(((size_t)b * a.np * NS) / 32);
     int blocks = (nunits + 7) / 8;
-    if (blocks > gp_num_cus()) blocks = gp_num_cus();  // persistent, one 8-wave workgroup per CU
+    const int per_cu = RING ? 1 : 2;  // persistent; the resident form (<= 90 KB of LDS, <= 128 registers for the 64-wide hidden layer) fits twice
+    if (blocks > gp_num_cus() * per_cu) blocks = gp_num_cus() * per_cu;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, a, nunits);
     return gp_launch_status();
 }
@@ -296,9 +307,12 @@ int gp_sa_pre_mlp_max_bf16x3(int b, int n, int np, int ns, int c1, int c2, int c
     if (b == 0) return GP_OK;
     SABfArgs a{n, np, zstride, zoff, xyz, new_xyz, z, idx, wxyz, bias1, reinterpret_cast<const bf16x8 *>(w2_split), bias2,
                reinterpret_cast<const bf16x8 *>(w3_split), bias3, out, cout_total, cout_off};
-    if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 32) return launch_bf16x3<128, 196, 256, 32>(a, b, (hipStream_t)s);
-    if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 16) return launch_bf16x3<128, 196, 256, 16>(a, b, (hipStream_t)s);
-    return GP_EINVAL;  // the level-2 shapes of the light encoder only (exploratory)
+    if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 32) return launch_bf16x3<128, 196, 256, 32, true>(a, b, (hipStream_t)s);
+    if (c1 == 128 && c2 == 196 && c3 == 256 && ns == 16) return launch_bf16x3<128, 196, 256, 16, true>(a, b, (hipStream_t)s);
+    if (c1 == 64 && c2 == 64 && c3 == 128 && ns == 16) return launch_bf16x3<64, 64, 128, 16, false>(a, b, (hipStream_t)s);
+    if (c1 == 64 && c2 == 96 && c3 == 128 && ns == 32) return launch_bf16x3<64, 96, 128, 32, false>(a, b, (hipStream_t)s);
+    if (c1 == 64 && c2 == 64 && c3 == 128 && ns == 32) return launch_bf16x3<64, 64, 128, 32, false>(a, b, (hipStream_t)s);
+    return GP_EINVAL;  // grouping levels 1 and 2 of the light / dense / lighter encoders (exploratory)
 }
 
 }  // extern "C"

@@ -41,7 +41,7 @@ class Pointnet2EncoderHIP:
         """arith: contraction convention of the squared distances in furthest point sampling and the ball queries ('A' | 'B' | 'C',
         config.DEFAULT_DIST_ARITH when None; include/genpose_hip.h GP_ARITH_*).
         precision: 'f32' (default: every dense layer on the fp32 matrix pipe - what all parity claims and the headline bench line run) or
-        'bf16x3' (OPT-IN, exploratory, round 5): the 128-196-256 grouping level on the bf16 matrix pipe as three-term split products with
+        'bf16x3' (OPT-IN, exploratory, round 5): grouping levels 1 and 2 (64-64/96-128, 128-196-256) on the bf16 matrix pipe as three-term split products with
         fp32 accumulation (csrc/sa_bf16x3.hip; ~2^-17 relative per product); centres and neighbourhoods are unaffected."""
         if precision not in ("f32", "bf16x3"):
             raise ValueError(f"encoder precision {precision!r}: 'f32' or 'bf16x3'")
@@ -58,6 +58,8 @@ class Pointnet2EncoderHIP:
         self._seen_once = ShapeCache(4 * self.MAX_PASS_GRAPHS)
 
     MAX_WORKSPACES = 12
+    # (layer widths, neighbourhood size) the opt-in split-bf16 kernel is instantiated for: grouping levels 1 and 2 (csrc/sa_bf16x3.hip)
+    BF16X3_SHAPES = {((128, 196, 256), 16), ((128, 196, 256), 32), ((64, 64, 128), 16), ((64, 96, 128), 32), ((64, 64, 128), 32)}
 
     def pin_workspaces(self, B, N, slot=0):
         """For whoever CAPTURES launches of this encoder in a hipGraph: the workspace of that geometry stays out of the eviction order
@@ -331,10 +333,10 @@ class Pointnet2EncoderHIP:
             off, zoff = 0, 0
             for i, sc in enumerate(scales):
                 (w1, b1), (w2, b2), (w3, b3) = sc.layers
-                if (self.precision == "bf16x3" and z is not None and sc.couts == [128, 196, 256] and nss[i] in (16, 32)
+                if (self.precision == "bf16x3" and z is not None and (tuple(sc.couts), nss[i]) in self.BF16X3_SHAPES
                         and (B * npnt * nss[i]) % 32 == 0):
                     w2s, b2s, w3s, b3s = sc.bf16x3_packs()
-                    _lib.call("gp_sa_pre_mlp_max_bf16x3", B, n, npnt, nss[i], 128, 196, 256, ptr(xyz), ptr(new_xyz), ptr(src["bq"][k][i]), ptr(z),
+                    _lib.call("gp_sa_pre_mlp_max_bf16x3", B, n, npnt, nss[i], sc.couts[0], sc.couts[1], sc.couts[2], ptr(xyz), ptr(new_xyz), ptr(src["bq"][k][i]), ptr(z),
                               zstride, zoff, ptr(sc.wxyz), ptr(b1), ptr(w2s), ptr(b2s), ptr(w3s), ptr(b3s), ptr(out), cout_total, off, st)
                     off += sc.couts[2]
                     zoff += sc.couts[0]

@@ -107,7 +107,7 @@ class SAScale:
         """Operands of the opt-in split-bf16 kernel (csrc/sa_bf16x3.hip) for layers 2 and 3: every weight as hi = bf16(w) and
         lo = bf16(w - hi), in the fragment order of v_mfma_f32_16x16x32_bf16 with the k order the register chain produces -
         k-block m = channels 32 m .. 32 m + 31, lane group g holds [32m + 4g .. +3] and [32m + 16 + 4g .. +3].
-        -> (w2 [KB1][NC2][2][64][8], b2 [32 KB2], w3 [2][KB2][8][2][64][8], b3) as int16 / float32 device tensors."""
+        -> (w2 [KB1][NC2][2][64][8], b2 [32 KB2], w3 [c3/128][KB2][8][2][64][8], b3) as int16 / float32 device tensors."""
         if self._bf16x3 is None:
             (_, _), (W2, b2), (W3, b3) = self._folded_plain
             c1, c2, c3 = self.couts
@@ -115,7 +115,7 @@ class SAScale:
             kb2 = (nc2 + 1) // 2
             w2 = pack_bf16x3(W2, nc2, c1 // 32)                                   # [KB1][NC2][2][64][8]
             w3 = pack_bf16x3(W3, c3 // 16, kb2)                                   # [KB2][16][2][64][8]
-            w3 = torch.stack([w3[:, :8], w3[:, 8:]], dim=0).contiguous()          # [half][KB2][8][2][64][8]: ring slice = (half, k-block)
+            w3 = torch.stack([w3[:, 8 * h:8 * h + 8] for h in range(c3 // 128)], dim=0).contiguous()  # [half][KB2][8][2][64][8]: slice = (half, k-block)
             b2p = torch.zeros(32 * kb2)
             b2p[:c2] = b2
             dev = self._device

@@ -13,16 +13,16 @@ from oracle import genpose_oracle as go
 GATE = 3e-5
 
 
-def _level2_fp64(enc, ws, B):
-    """Level 2 (both scales) of the light encoder in float64 on the host, from the folded weights and the device's own level-1 output,
-    centres and neighbourhoods: h1 = relu(W1f feat_j + W1x (x_j - c) + b1) -> relu(W2 h1 + b2) -> max_j relu(W3 h2 + b3)."""
-    xyz = ws["new_xyz"][1][:B].double().cpu()      # [B,256,3] level-1 centres = level 2's points
-    feat = ws["feat"][1][:B].double().cpu()        # [B,256,256]
-    centres = ws["new_xyz"][2][:B].double().cpu()  # [B,128,3]
+def _level_fp64(enc, ws, B, k=2, feat_in=None):
+    """Grouping level k (both scales) of the light encoder in float64 on the host, from the folded weights and the device's own level k-1
+    output (or `feat_in`), centres and neighbourhoods: h1 = relu(W1f feat_j + W1x (x_j - c) + b1) -> relu(W2 h1 + b2) -> max_j relu(W3 h2 + b3)."""
+    xyz = ws["new_xyz"][k - 1][:B].double().cpu()      # level k-1's centres = level k's points
+    feat = (ws["feat"][k - 1][:B] if feat_in is None else feat_in[:B]).double().cpu()
+    centres = ws["new_xyz"][k][:B].double().cpu()
     outs = []
-    for i, sc in enumerate(enc.w.levels[2]):
+    for i, sc in enumerate(enc.w.levels[k]):
         (W1, b1), (W2, b2), (W3, b3) = [(W.double(), b.double()) for W, b in sc._folded_plain]  # W1 columns: [feat..., dx, dy, dz]
-        idx = ws["bq"][2][i][:B].long().cpu()      # [B,128,ns]
+        idx = ws["bq"][k][i][:B].long().cpu()      # [B,np,ns]
         bi = torch.arange(B)[:, None, None]
         nf = feat[bi, idx]                          # [B,128,ns,256]
         d = xyz[bi, idx] - centres[:, :, None, :]   # [B,128,ns,3]
@@ -30,7 +30,11 @@ def _level2_fp64(enc, ws, B):
         h2 = torch.relu(h1 @ W2.t() + b2)
         h3 = torch.relu(h2 @ W3.t() + b3)
         outs.append(h3.max(dim=2)[0])
-    return torch.cat(outs, dim=-1)  # [B,128,512]
+    return torch.cat(outs, dim=-1)  # [B,np,2 x c3]
+
+
+def _level2_fp64(enc, ws, B):
+    return _level_fp64(enc, ws, B, 2)
 
 
 def test_bf16x3_level_against_fp64_and_fp32():
@@ -40,20 +44,22 @@ def test_bf16x3_level_against_fp64_and_fp32():
     e32, ebf = Pointnet2EncoderHIP(sd, "cuda"), Pointnet2EncoderHIP(sd, "cuda", precision="bf16x3")
     pts = torch.from_numpy(synth.make_batch(6, start=1234)).cuda()
     f32, w32 = e32.forward(pts, return_intermediates=True)
-    f32, l2_32 = f32.clone(), w32["feat"][2].clone()
+    f32 = f32.clone()
+    l_32 = {k: w32["feat"][k].clone() for k in (0, 1, 2)}
     fbf, wbf = ebf.forward(pts, return_intermediates=True)
-    l2_bf = wbf["feat"][2].clone()
+    l_bf = {k: wbf["feat"][k].clone() for k in (0, 1, 2)}
     for k in range(3):  # the grouping does not depend on the precision
         assert torch.equal(w32["fps_idx"][k], wbf["fps_idx"][k]) and all(torch.equal(a, b) for a, b in zip(w32["bq"][k], wbf["bq"][k]))
-    for k in (0, 1):    # nor do the levels that stay on the fp32 pipe
-        assert torch.equal(w32["feat"][k], wbf["feat"][k])
-    ref = _level2_fp64(e32, w32, 3)
-    scale = float(ref.abs().max())
-    e_32 = float((l2_32[:3].double().cpu() - ref).abs().max()) / scale
-    e_bf = float((l2_bf[:3].double().cpu() - ref).abs().max()) / scale
-    print(f"level 2 vs fp64, max error / feature scale: fp32 pipe {e_32:.2e}, split bf16 {e_bf:.2e} (gate {GATE:.0e})")
-    assert e_32 < 3e-6 and e_bf < GATE, (e_32, e_bf)
-    assert not torch.equal(l2_32, l2_bf)  # (it IS a different arithmetic)
+    assert torch.equal(l_32[0], l_bf[0])  # nor does level 0, which stays on the fp32 pipe
+    for k in (1, 2):
+        # each level against fp64 ON ITS OWN INPUT (the split kernel's level 2 reads the split kernel's level 1)
+        ref32, refbf = _level_fp64(e32, w32, 3, k, l_32[k - 1]), _level_fp64(e32, w32, 3, k, l_bf[k - 1])
+        scale = float(ref32.abs().max())
+        e_32 = float((l_32[k][:3].double().cpu() - ref32).abs().max()) / scale
+        e_bf = float((l_bf[k][:3].double().cpu() - refbf).abs().max()) / scale
+        print(f"level {k} vs fp64, max error / feature scale: fp32 pipe {e_32:.2e}, split bf16 {e_bf:.2e} (gate {GATE:.0e})")
+        assert e_32 < 3e-6 and e_bf < GATE, (k, e_32, e_bf)
+        assert not torch.equal(l_32[k], l_bf[k])  # (it IS a different arithmetic)
     # end of the encoder: the deviation stays at that level through the GroupAll level
     d = float((fbf - f32).abs().max()) / float(f32.abs().max())
     assert d < 5 * GATE, d
