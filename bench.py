@@ -290,6 +290,7 @@ def main():
             side["drop_in_eval_single"] = drop_in_leg(torch, str(dev), K)
             side["config0_single_object"] = config0_leg(torch, str(dev))
             side["energy_model_pc_step"] = energy_model_leg(torch, str(dev), B, K, G)
+            side["encoder_split_bf16"] = encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev))
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
@@ -501,6 +502,54 @@ def one_batch_leg(torch, score_agent, pool, B, K, n):
     r = pc_roofline(torch, p1._sampler(0, 1), B * K, n)
     return {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "kernel": r["kernel"],
             "rows_per_launch": B * K, "avg_launch_us": r["avg_launch_us"], "frac": r["frac"]}
+
+
+def encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, dev):
+    """OPT-IN, EXPLORATORY (round 5; csrc/sa_bf16x3.hip): the headline workload with grouping levels 1 and 2 of the encoder on the bf16
+    matrix pipe as three-term split products (a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo, fp32 accumulate).  A SEPARATE leg: the headline
+    `value` above is pure fp32.  Reported with its measured deviation: encoder features against the fp32 kernels' on the same clouds
+    (centres and neighbourhoods are bit-identical: they depend on coordinates only).  The sampler trunk stays on the fp32 pipe."""
+    from genpose_amd.config import get_config
+    from genpose_amd.pipeline import PipelinedPCPredictor
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.weights_synth import make_state_dict
+    agent = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=["pc"], sampling_steps=n, encoder_precision="bf16x3"))
+    agent.load_state_dict(make_state_dict(0, "score"))
+    pipe = PipelinedPCPredictor(agent, B, K, n, batches_per_launch=G)
+    batches = lambda count: [pool[j % len(pool)] for j in range(count)]
+    pipe.run(batches(G))
+    pipe.run(batches(G))
+    torch.cuda.synchronize()
+    times = []
+    nb = 2 * G
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _o in pipe.run(batches(nb)):
+            pass
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    big = torch.cat(batches(G), dim=0)
+    f32 = score_agent.net.pts_encoder.forward(big).clone()
+    fbf = agent.net.pts_encoder.forward(big).clone()
+    scale = float(f32.abs().max())
+    d = (fbf - f32).abs()
+    reps = 10
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for enc_, a, b in ((score_agent.net.pts_encoder, ev[0], ev[1]), (agent.net.pts_encoder, ev[2], ev[3])):
+        for _ in range(3):
+            enc_.encode(big)
+        a.record()
+        for _ in range(reps):
+            enc_.encode(big)
+        b.record()
+    torch.cuda.synchronize()
+    return {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "batches_per_launch": G,
+            "dtype": "f32 via 3 x bf16 split products, fp32 accumulate (encoder grouping levels 1-2); everything else f32",
+            "opt_in": "cfg.encoder_precision = 'bf16x3' (default 'f32')",
+            "encoder_pass_ms": {"clouds": int(big.shape[0]), "f32": round(ev[0].elapsed_time(ev[1]) / reps, 3), "bf16x3": round(ev[2].elapsed_time(ev[3]) / reps, 3)},
+            "feature_deviation_vs_f32": {"max_abs_over_scale": float(d.max()) / scale, "rms_over_scale": float(d.pow(2).mean().sqrt()) / scale,
+                                         "clouds": int(big.shape[0]), "note": "per-level error against fp64: tests/test_gpu_bf16x3.py, profiles/r5_bf16x3_gate.txt"}}
 
 
 def ode_leg(torch, B, K, G, T0, pool, dev):
