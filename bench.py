@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--only-drop-in", action="store_true",
                     help="run only the `drop_in_eval_single` leg (the reference's eval_single call sequence through the agent API) and print it - "
                          "for rocprofv3 kernel statistics of that path")
+    ap.add_argument("--only-split-bf16", action="store_true", help="run only the opt-in split-bf16 encoder leg (and print it)")
     ap.add_argument("--tracking", action="store_true",
                     help="BASELINE configs[4]: tracking mode - every rank streams --sequences whole sequences (warm-started candidates, PF-ODE "
                          "sampler from T0 = 0.15, energy ranking, aggregation per frame); a step = one frame of every sequence")
@@ -279,6 +280,9 @@ def main():
         else:
             nfev = int(score_agent.net.last_sampler.last_stats["nfev"])
 
+    if args.only_split_bf16:
+        print(json.dumps({"headline_f32": round(value, 2), "encoder_split_bf16": encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev))}), flush=True)
+        return
     side = {}
     if rank == 0 and world == 1:
         # the same workload with ONE batch per launch (no request batching), reported next to the headline for comparison
@@ -515,14 +519,15 @@ def encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, dev):
     from genpose_amd.weights_synth import make_state_dict
     agent = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=["pc"], sampling_steps=n, encoder_precision="bf16x3"))
     agent.load_state_dict(make_state_dict(0, "score"))
-    pipe = PipelinedPCPredictor(agent, B, K, n, batches_per_launch=G)
+    pipe = PipelinedPCPredictor(agent, B, K, n, batches_per_launch=G, overlap=False)  # one stream, like the headline run
     batches = lambda count: [pool[j % len(pool)] for j in range(count)]
     pipe.run(batches(G))
     pipe.run(batches(G))
     torch.cuda.synchronize()
+    pipe.timing = True
     times = []
     nb = 2 * G
-    for _ in range(5):
+    for _ in range(7):
         t0 = time.perf_counter()
         for _o in pipe.run(batches(nb)):
             pass
@@ -544,7 +549,9 @@ def encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, dev):
             enc_.encode(big)
         b.record()
     torch.cuda.synchronize()
+    in_situ = pipe.sampler_launch_seconds()
     return {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "batches_per_launch": G,
+            "sampler_in_situ_avg_launch_us": round(in_situ * 1e6, 2) if in_situ else None,
             "dtype": "f32 via 3 x bf16 split products, fp32 accumulate (encoder grouping levels 1-2); everything else f32",
             "opt_in": "cfg.encoder_precision = 'bf16x3' (default 'f32')",
             "encoder_pass_ms": {"clouds": int(big.shape[0]), "f32": round(ev[0].elapsed_time(ev[1]) / reps, 3), "bf16x3": round(ev[2].elapsed_time(ev[3]) / reps, 3)},
