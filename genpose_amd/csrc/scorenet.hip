@@ -171,10 +171,15 @@ struct PcArgs {
     const float *gn_ext;             // [nsteps][ngroups] or null: the batch's gradient-norm statistic supplied from outside (a batch that is
     int ngroups;                     //   sharded over several GPUs, all-reduced between the launches): the SUM of |score| over all its
     float gn_rows;                   //   rows when gn_rows > 0 (= that row count), else the mean itself
-    // head-split plan (GP_PLAN_HEADSPLIT): workgroup 3 t + h evaluates head h of 16-row tile t and writes components 3 h .. 3 h + 2 of the
-    // score; a row's norm needs all nine, so the partial sums are per ROW AND HEAD - partials [nsteps][3 * rows], entry 3 r + h = the sum of
-    // squares of row r's three components of head h - and the next launch reduces sqrt(p[3r] + p[3r+1] + p[3r+2]) over its batch's rows.
-    // (nparts = 3 * nrows, ppg = 3 * rows_per_group; wgpg counts TILES per group.)
+    // head-split plan (GP_PLAN_HEADSPLIT): workgroup 3 t + h evaluates head h of 16-row tile t and owns components 3 h .. 3 h + 2 of the
+    // score.  THREE workgroups read a tile's state and score and each writes a part of them, so nothing a launch reads may be written by
+    // the same launch: every step keeps its own copies in its row of `partials` (nparts = 21 * nrows floats per step):
+    //     [0, 3R)     sum of squares of row r's three components of head h at 3 r + h (a row's norm needs all nine: the NEXT launch puts
+    //                 sqrt(p[3r] + p[3r+1] + p[3r+2]) together and reduces it over its batch's rows)
+    //     [3R, 12R)   score_i [R][9], read by launch i + 1
+    //     [12R, 21R)  the state after launch i's update [R][9], read by launch i + 1 (launch 1 reads the initial state from `x`, which
+    //                 this plan never writes)
+    // (wgpg counts TILES per group.)
 };
 
 // Kernel for step i (0 <= i <= nsteps):
@@ -196,6 +201,16 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
     __shared__ float s_gn;
     const int tile = SPLIT ? blockIdx.x / 3 : blockIdx.x, hsel = SPLIT ? blockIdx.x - 3 * tile : 0;
     const int row0 = tile * P, tid = threadIdx.x, i = a.step;
+    // SPLIT: three workgroups READ a tile's state and score and each writes a part - in place that would be a race between workgroups
+    // (a workgroup dispatched late would read what a sibling has already written).  Launch i reads step i-1's copies and writes its own
+    // (PcArgs).  The finish-only launch needs one workgroup per tile.
+    if (SPLIT && i == a.nsteps && hsel != 0) return;
+    const size_t R = (size_t)a.nrows;
+    const float *prev = SPLIT && i > 0 ? a.partials + (size_t)(i - 1) * a.nparts : nullptr;
+    float *mine = SPLIT && i < a.nsteps ? a.partials + (size_t)i * a.nparts : nullptr;
+    const float *x_in = SPLIT ? (i <= 1 ? a.x : prev + 12 * R) : a.x;
+    const float *score_in = SPLIT && i > 0 ? prev + 3 * R : a.score;
+    float *x_out = SPLIT ? (mine ? mine + 12 * R : nullptr) : a.x;
     TrunkPre<P> pre;
     float sigma = 1.f;
     if (i < a.nsteps) {
@@ -216,8 +231,8 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
             const float *z2 = a.z_pred + ((size_t)(i - 1) * a.nrows + r) * 9;
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
-                xv[j] = a.x[(size_t)r * 9 + j];
-                gr[j] = a.score[(size_t)r * 9 + j];
+                xv[j] = x_in[(size_t)r * 9 + j];
+                gr[j] = score_in[(size_t)r * 9 + j];
                 zz1[j] = z1[j];
                 zz2[j] = z2[j];
             }
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
             }
         } else if (tid >= LASTW) {
             float s = 0.f;
-            const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)(tile / a.wgpg) * a.ppg;
+            const float *pp = a.partials + (size_t)(i - 1) * a.nparts + (size_t)(tile / a.wgpg) * (SPLIT ? 3 * a.rows_per_group : a.ppg);
             if constexpr (SPLIT) {
                 for (int r = tid - LASTW; r < a.rows_per_group; r += 64) s += sqrtf((pp[3 * r] + pp[3 * r + 1]) + pp[3 * r + 2]);
             } else {
@@ -254,7 +269,10 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
                     for (int j = 0; j < 3; ++j) tr[6 + j] = xv[6 + j] + cen[j];
                 }
 #pragma unroll
-                for (int j = 0; j < 9; ++j) a.x[(size_t)r * 9 + j] = xv[j];
+                if (x_out) {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) x_out[(size_t)r * 9 + j] = xv[j];
+                }
                 if (i == a.nsteps) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) mx[6 + j] += cen[j];
@@ -285,7 +303,10 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
             if (SPLIT && j / 3 != hsel) continue;
             const float v = F[r * ldf + j] / (sigma + 1e-7f);
             F[r * ldf + j] = v;
-            if (row0 + r < a.nrows) a.score[(size_t)(row0 + r) * POSE + j] = v;
+            if (row0 + r < a.nrows) {
+                a.score[(size_t)(row0 + r) * POSE + j] = v;  // (an output only under the head-split plan: nothing reads it back)
+                if (SPLIT) mine[3 * R + (size_t)(row0 + r) * POSE + j] = v;
+            }
         }
     } else {
         F = const_cast<float *>(gp_bwd::score_vjp_tile<gp_bwd::ENERGY>(lds, net, a.cvec, a.tvec_all + (size_t)i * HEADS, row0, a.nrows, a.kcand, pre, sigma));
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
         // per row: the sum of squares of this head's three components (the row's norm is put together by the next launch)
         if (tid < P && row0 + tid < a.nrows) {
             const float *f = F + tid * ldf + 3 * hsel;
-            a.partials[(size_t)i * a.nparts + 3 * (size_t)(row0 + tid) + hsel] = (f[0] * f[0] + f[1] * f[1]) + f[2] * f[2];
+            mine[3 * (size_t)(row0 + tid) + hsel] = (f[0] * f[0] + f[1] * f[1]) + f[2] * f[2];
         }
         return;
     }
@@ -582,7 +603,7 @@ int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k,
     if (P == (16 | GP_PLAN_HEADSPLIT)) {  // three workgroups per 16-row tile, one head each: one partial per row and head (PcArgs)
         if (model != 0 || (ngroups > 1 && rg % 16 != 0)) return GP_EINVAL;
         *tile_out = P;
-        *nparts_out = 3 * ngroups * rg;
+        *nparts_out = 21 * ngroups * rg;  // per step: row-and-head sums of squares [3R], score [9R], state [9R] (PcArgs)
         return GP_OK;
     }
     if (P != 16 && P != 32 && P != 64 && P != 128) return GP_EINVAL;

@@ -277,9 +277,10 @@ int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int 
  * 16 / 32 / 64 / 128 as in gp_score_eval_plan.  *tile_out = the plan taken, *nparts_out = partial sums of |score| per step
  * (`partials` must hold nsteps * nparts floats: one per workgroup in the tile form, one per wave in the chain form).  GP_EINVAL when a
  * workgroup of the plan would straddle two groups.  In the latency regime (score model, tiles x 3 <= CUs) the automatic choice is
- * 16 | GP_PLAN_HEADSPLIT (defined with the RK45 driver below): three workgroups per 16-row tile, one head of the network each; its
- * partials are per row and head (nparts = 3 x rows: sums of squares of a head's three score components, put together by the next
- * launch), and it refuses gn_ext (a sharded batch's caller sums per-tile partials: force tile = 16 there). */
+ * 16 | GP_PLAN_HEADSPLIT (defined with the RK45 driver below): three workgroups per 16-row tile, one head of the network each; in its
+ * `partials` every step keeps, per row, the three heads' sums of squares AND its own copies of the score and the state (nparts = 21 x rows:
+ * three workgroups read a tile's state and score and each writes a part, so nothing a launch reads is written by the same launch; `x`
+ * keeps the INITIAL state), and it refuses gn_ext (a sharded batch's caller sums per-tile partials: force tile = 16 there). */
 int gp_pc_layout(int model, int tile, int ngroups, int nclouds_per_group, int k, int *tile_out, int *nparts_out);
 /* gp_pc_step_coupled with the plan chosen by the caller (tile as above; 0 = automatic; every launch of one chain must use the same
  * plan) and the MODEL whose score drives the sampler: 0 = the score network (f / (sigma + 1e-7), scorenet.py:217); 1 = the ENERGY

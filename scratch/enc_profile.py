@@ -8,7 +8,8 @@ from genpose_amd.encoder import Pointnet2EncoderHIP
 from genpose_amd.weights_synth import make_state_dict
 B = int(sys.argv[1]); iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 mode = sys.argv[3] if len(sys.argv) > 3 else "forward"
-enc = Pointnet2EncoderHIP(make_state_dict(0, "score"), "cuda")
+prec = sys.argv[4] if len(sys.argv) > 4 else os.environ.get("GP_ENC_PRECISION", "f32")
+enc = Pointnet2EncoderHIP(make_state_dict(0, "score"), "cuda", precision=prec)
 pts = torch.from_numpy(synth.make_batch(B)).cuda()
 run = {"forward": lambda: enc.forward(pts), "pass": lambda: enc.encode(pts, use_graph=False)[0], "graph": lambda: enc.encode(pts)[0]}[mode]
 for _ in range(3): run()
@@ -18,4 +19,4 @@ e0.record()
 for _ in range(iters): run()
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / iters
-print(f"encoder B={B} [{mode}]: {t:.3f} ms per pass = {B * 2.201 / t:.1f} TFLOP/s on the reference count")
+print(f"encoder B={B} [{mode}, {prec}]: {t:.3f} ms per pass = {B * 2.201 / t:.1f} TFLOP/s on the reference count")

@@ -9,7 +9,7 @@ from genpose_amd.weights_synth import make_state_dict
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 sd = make_state_dict(0, "score")
-enc = Pointnet2EncoderHIP(sd, "cuda"); net = ScoreNetHIP(sd, "cuda")
+enc = Pointnet2EncoderHIP(sd, "cuda", precision=os.environ.get("GP_ENC_PRECISION", "f32")); net = ScoreNetHIP(sd, "cuda")
 pts = torch.from_numpy(synth.make_batch(B)).cuda()
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()

@@ -44,7 +44,7 @@ def test_plan_rule():
     assert lib.gp_rk45_plan_rows(0, 1, 256, 50) in (32, 64)
     assert lib.gp_rk45_plan_rows(1, 1, 5, 50) == 16 and lib.gp_rk45_plan_rows(2, 1, 5, 50) == 16  # forward + backward right-hand sides: tiles
     t, n = ctypes.c_int(0), ctypes.c_int(0)
-    assert lib.gp_pc_layout(0, 0, 1, 5, 50, ctypes.byref(t), ctypes.byref(n)) == 0 and t.value == 16 | HS and n.value == 3 * 250
+    assert lib.gp_pc_layout(0, 0, 1, 5, 50, ctypes.byref(t), ctypes.byref(n)) == 0 and t.value == 16 | HS and n.value == 21 * 250
     assert lib.gp_pc_layout(0, 16, 1, 5, 50, ctypes.byref(t), ctypes.byref(n)) == 0 and t.value == 16 and n.value == 16
     assert lib.gp_pc_layout(1, 16 | HS, 1, 5, 50, ctypes.byref(t), ctypes.byref(n)) == -1  # the energy model's score: no head-split
     assert lib.gp_pc_tile_rows(1, 5, 50) == 16  # the legacy entry points stay on whole tiles
