@@ -268,7 +268,6 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void pc_step_kernel(PcArgs a, gp_s
 #pragma unroll
                     for (int j = 0; j < 3; ++j) tr[6 + j] = xv[6 + j] + cen[j];
                 }
-#pragma unroll
                 if (x_out) {
 #pragma unroll
                     for (int j = 0; j < 9; ++j) x_out[(size_t)r * 9 + j] = xv[j];
