@@ -166,3 +166,38 @@ def test_agent_calls_take_the_plan_and_a_sharded_batch_does_not(nets):
     finally:
         if made:
             dist.destroy_process_group()
+
+
+def test_split_plan_under_contention_is_bit_stable(nets):
+    """Three workgroups serve a tile: each reads the tile's whole state and score and writes a part.  Nothing a launch reads may be
+    written by the same launch (a sibling dispatched late - other streams own the CUs - would read what another has already written;
+    an in-place version of this plan passed every quiet test and failed next to a busy encoder stream).  Every step therefore keeps
+    its own copies (PcArgs, csrc/scorenet.hip).  Here: the sampler's graph replayed while an encoder pass of 256 clouds hammers the chip
+    on another stream, 20 times - every replay must give the bits of the undisturbed run; the RK45 driver likewise."""
+    from genpose_amd import synth
+    from genpose_amd.encoder import Pointnet2EncoderHIP
+    from genpose_amd.samplers import ODESampler, PCSampler
+    sd, net = nets
+    B, K, n = 6, 50, 25
+    feat, centre, x0, z1, z2 = _inputs(B, K, n, seed=99)
+    cvec = net.cloud_embed(feat.cuda())
+    smp = PCSampler(net, B, K, n, "cuda", tile=16 | HS)
+    quiet = smp.run(cvec, centre.cuda(), x0.cuda(), z1.cuda(), z2.cuda())[1].clone()
+    ode = ODESampler(net, B, K, "cuda", tile=16 | HS)
+    y0 = (x0 / 50.0 * float(go.ve_sigma(0.15))).cuda()
+    quiet_ode = ode.run(cvec, centre.cuda(), y0, 0.15)[1].clone()
+    enc = Pointnet2EncoderHIP(sd, "cuda")
+    big = torch.from_numpy(synth.make_batch(256, start=5000)).cuda()
+    side = torch.cuda.Stream()
+    enc.forward(big)
+    torch.cuda.synchronize()
+    for rep in range(20):
+        with torch.cuda.stream(side):
+            enc.forward(big)  # ~4 ms of kernels that fill every CU
+        got = smp.run(cvec, centre.cuda(), x0.cuda(), z1.cuda(), z2.cuda())[1]
+        assert torch.equal(got, quiet), f"PC replay {rep} beside a busy stream"
+        if rep % 5 == 0:
+            with torch.cuda.stream(side):
+                enc.forward(big)
+            assert torch.equal(ode.run(cvec, centre.cuda(), y0, 0.15)[1], quiet_ode), f"ODE solve {rep} beside a busy stream"
+    torch.cuda.synchronize()
