@@ -477,7 +477,7 @@ def pc_roofline(torch, smp, rows, n, flop_row=FLOP_SCORE_ROW):
                 "flops_per_launch": flops_per_launch}
     # HBM-side bytes per launch come from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in separate
     # rocprofv3 runs, gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); only valid for the profiled shape
-    for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tpath):
             continue
