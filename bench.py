@@ -294,7 +294,10 @@ def main():
             side["drop_in_eval_single"] = drop_in_leg(torch, str(dev), K)
             side["config0_single_object"] = config0_leg(torch, str(dev))
             side["energy_model_pc_step"] = energy_model_leg(torch, str(dev), B, K, G)
-            side["encoder_split_bf16"] = encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev))
+            try:  # an optional, exploratory leg must never cost the line
+                side["encoder_split_bf16"] = encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev))
+            except Exception as exc:  # noqa: BLE001
+                side["encoder_split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
@@ -783,6 +786,7 @@ def run_cpu_baseline(torch, args, K, n):
     optima differ), and the end-to-end sample (encoder + sampler, what `value` reports) runs each stage at ITS best count."""
     from genpose_amd import synth
     from oracle import genpose_oracle as go
+    from oracle import parallel as opar
     from oracle import pn2_oracle as ops
     Bc = args.cpu_clouds
     budget = args.cpu_budget
@@ -840,7 +844,6 @@ def run_cpu_baseline(torch, args, K, n):
         # one process with many threads does not scale on its small convolutions - 64 threads are slower than 32 - several processes
         # with 8 threads each do); taken when it is faster.  The sampler's rows are coupled through the batch-mean score norm every
         # step: one process.
-        from oracle import parallel as opar
         pool_workers, pool_threads = opar._plan()
         enc_pool_s, pool_same = None, None
         if pool_workers > 1 and Bc >= 32:

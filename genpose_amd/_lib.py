@@ -66,6 +66,8 @@ SIGNATURES = {
     "gp_pc_layout": [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "gp_pc_step_plan": [c_int, c_int, c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 12 + [c_int, P],
     "gp_score_eval_plan": [c_int, c_int, c_int, NETP, P, P, P, P, c_int, P, P],
+    "gp_pc_layout_bf16x3": [c_int, c_int, c_int, ctypes.POINTER(c_int)],
+    "gp_pc_step_bf16x3": [c_int] * 5 + [P] * 18 + [P],
     "gp_pc_step_grouped": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 11 + [P],
     "gp_pc_step_coupled": [c_int, c_int, c_int, c_int, c_int, NETP] + [P] * 12 + [P],
     "gp_rk45_state_bytes": [],

@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 TAG = os.environ.get("GP_BUILD_TAG", "")
 SO = os.path.join(LIBDIR, f"libgenpose_hip_{TAG}.so" if TAG else "libgenpose_hip.so")
 OBJDIR = os.path.join(LIBDIR, f"obj_{TAG}") if TAG else LIBDIR
-SOURCES = ["misc.hip", "pn2_ops.hip", "sa_mlp.hip", "scorenet.hip", "rk45.hip", "rank.hip", "preprocess.hip", "score_div.hip", "sa_bf16x3.hip"]
+SOURCES = ["misc.hip", "pn2_ops.hip", "sa_mlp.hip", "scorenet.hip", "rk45.hip", "rank.hip", "preprocess.hip", "score_div.hip", "sa_bf16x3.hip", "trunk_bf16x3.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
 FLAGS += [f for f in os.environ.get("GP_EXTRA_FLAGS", "").split() if f]
 

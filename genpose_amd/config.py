@@ -26,6 +26,7 @@ DEFAULTS = dict(
     pooling_mode="nearest", ranker="energy_ranker", score_model_dir="", energy_model_dir="", result_dir="", test_source="Real",
     save_video=False, is_train=False, use_pretrain=False, log_dir="debug", parallel=False, seed=0,
     # pre-processing / evaluation side (preprocess.py, evaluation.py): configs/config.py:8,72-78
+    sampler_precision="f32",  # (ours) 'bf16x3': opt-in, exploratory split-bf16 products in the PC sampler's score network (csrc/trunk_bf16x3.hip)
     encoder_precision="f32",  # (ours) 'bf16x3': opt-in, exploratory split-bf16 products on the 128-196-256 grouping level (csrc/sa_bf16x3.hip)
     dist_arith=DEFAULT_DIST_ARITH,  # (ours) contraction convention of the grouping operators' distances, see above
     synset_names=["bottle", "bowl", "camera", "can", "laptop", "mug"], img_size=256, max_eval_num=10000000, results_path="",

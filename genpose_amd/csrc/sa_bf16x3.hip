@@ -17,13 +17,11 @@
 //     (weights.py: pack_bf16x3);
 //   * layer 3 in halves of eight output chunks (64 accumulator registers for the two sub-chunks), ring slice = (half, k-block) = 16 KB;
 //   * level 1 (64-64/96-128: all weights fit LDS) runs the same kernel without the ring and without a barrier in the loop.
-#include "gp_common.h"
+#include "bf16x3.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+using namespace gp_bf16x3;
 
 struct SABfArgs {
     int n, np, zstride, zoff;
@@ -37,20 +35,6 @@ struct SABfArgs {
     float *out;
     int cout_total, cout_off;
 };
-
-// (a, b) = the D fragments of chunks 2m and 2m+1 (post-ReLU) -> the lane's eight k-values of k-block m as hi / lo bf16 vectors
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8 &hi, bf16x8 &lo) {
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-        const bf16x2 h = __builtin_convertvector(f32x2{x[i], x[i + 1]}, bf16x2);  // v_cvt_pk_bf16_f32 (round to nearest even)
-        const f32x2 hf = __builtin_convertvector(h, f32x2);
-        const bf16x2 l = __builtin_convertvector(f32x2{x[i] - hf.x, x[i + 1] - hf.y}, bf16x2);  // x - hi is exact in fp32
-        hi[i] = h.x, hi[i + 1] = h.y, lo[i] = l.x, lo[i + 1] = l.y;
-    }
-}
-
-__device__ __forceinline__ f32x4 relu4(const f32x4 v) { return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
 
 // RING: layer-3 weights through the 3-slot ring (level 2: 224 KB of them); !RING: they are LDS-resident too and the loop has no barrier
 // (level 1: 64-64/96-128, 32-48 KB) - sa_chain_lds_kernel's form.

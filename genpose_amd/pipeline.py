@@ -54,7 +54,8 @@ class PipelinedPCPredictor:
         # (sampler_streams > 1 puts several sampler chains in flight; measured SLOWER at the bench configuration:
         #  13.1 k vs 14.2 k poses/s - the chains contend for the same MFMA pipes and each step boundary gets longer)
         self.s_smp = [torch.cuda.Stream(self.dev, priority=-1) for _ in range(sampler_streams)] if overlap else [self.s_enc]
-        self.smp = [{self.G: PCSampler(self.net.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False, groups=self.G)}
+        self.smp = [{self.G: PCSampler(self.net.pose_score_net, B, K, num_steps, self.dev, use_graph=True, record_traj=False, groups=self.G,
+                                       precision=self.net._pc_precision(B, K, groups=self.G))}
                     for _ in range(sampler_streams)]
         # furthest point sampling of the NEXT launch group runs on a side stream while the MFMA stages of the current group
         # own the chip: it is a latency-bound chain of 893 block-wide argmax steps per cloud (one workgroup per cloud, tiny
@@ -78,7 +79,8 @@ class PipelinedPCPredictor:
 
     def _sampler(self, j, g):
         if g not in self.smp[j]:  # ragged tail of a run: fewer batches in the last launch
-            self.smp[j][g] = PCSampler(self.net.pose_score_net, self.B1 * g, self.K, self.n, self.dev, use_graph=True, record_traj=False, groups=g)
+            self.smp[j][g] = PCSampler(self.net.pose_score_net, self.B1 * g, self.K, self.n, self.dev, use_graph=True, record_traj=False, groups=g,
+                                       precision=self.net._pc_precision(self.B1 * g, self.K, groups=g))
         return self.smp[j][g]
 
     def run(self, batches, prior_noise=None, noise=None, out=None):

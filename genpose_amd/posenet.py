@@ -114,6 +114,13 @@ class GFObjectPose:
         ev.record()
         return dev
 
+    def _pc_precision(self, B, K, coupling=None, groups=1):
+        """cfg.sampler_precision = 'bf16x3' (opt-in, exploratory): the PC sampler's score network on split-bf16 products where the 128-row
+        launch plan applies (>= 43 candidates per cloud, uncoupled); anything else keeps the fp32 kernels."""
+        if getattr(self.cfg, "sampler_precision", "f32") != "bf16x3" or coupling is not None or K < 43:
+            return "f32"
+        return "bf16x3" if groups == 1 or ((B // groups) * K) % 128 == 0 else "f32"
+
     def sample(self, data, sampler, init_x=None, T0=None, noise=None, return_process=True):
         self._need_weights()
         cvec, K = self._rows(data)
@@ -134,7 +141,7 @@ class GFObjectPose:
                 # self.coupling_group (optional, set by the caller): the batch is sharded over the ranks of that process group and
                 # the Langevin step size is taken over ALL of its rows (PCSampler, "faithful" multi-GPU mode)
                 smp = self._samplers[key] = PCSampler(self.pose_score_net, B, K, n, self.device, record_traj=return_process,
-                                                      coupling_group=coupling)
+                                                      coupling_group=coupling, precision=self._pc_precision(B, K, coupling))
             z1, z2 = noise if noise is not None else (None, None)
             self.last_sampler = smp  # statistics / timing of the sampler that served the last call
             xs, res = smp.run(cvec, centre, x0, z1, z2)

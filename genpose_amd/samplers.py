@@ -25,7 +25,8 @@ def pc_schedule(num_steps, eps=EPS):
 class PCSampler:
     """Predictor-corrector sampler state for a fixed (B, K, num_steps): buffers + optional hipGraph of the whole loop."""
 
-    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1, coupling_group=None, tile=0, model="score"):
+    def __init__(self, net, B, K, num_steps, device, use_graph=True, record_traj=False, groups=1, coupling_group=None, tile=0, model="score",
+                 precision="f32"):
         """B clouds in `groups` independent batches of B/groups clouds laid out back to back: one launch chain serves all of
         them, the batch-mean gradient norm (samplers.py:130-132) stays per batch (gp_pc_step_grouped).
 
@@ -39,6 +40,13 @@ class PCSampler:
             raise ValueError(f"{B} clouds do not split into {groups} equal batches")
         if model not in ("score", "energy"):
             raise ValueError(model)
+        # precision 'bf16x3' (OPT-IN, exploratory; csrc/trunk_bf16x3.hip): the trunk's dense layers as three-term bf16 split products with
+        # fp32 accumulation, 128-row workgroups.  Score model, no cross-rank coupling; never the default.
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError(f"sampler precision {precision!r}: 'f32' or 'bf16x3'")
+        if precision == "bf16x3" and (model != "score" or coupling_group is not None or tile):
+            raise NotImplementedError("the split-bf16 PC step serves the score model, uncoupled, on its own launch plan")
+        self.precision = precision
         # model 'energy': `net` holds the ENERGY network's weights and the sampler is driven by ITS score - the gradient of the
         # inner-product energy (posenet.py:94-130 on a PoseEnergyNet), evaluated inside the step kernel (forward + vector-Jacobian product)
         self.model = 0 if model == "score" else 1
@@ -50,7 +58,12 @@ class PCSampler:
         # through an LDS ring) for launches of ~32 000 rows and more; `tile` forces one (tests, measurements)
         import ctypes
         t_out, n_out = ctypes.c_int(0), ctypes.c_int(0)
-        if _lib.lib().gp_pc_layout(self.model, int(tile), groups, B // groups, K, ctypes.byref(t_out), ctypes.byref(n_out)) != 0:
+        if precision == "bf16x3":
+            if _lib.lib().gp_pc_layout_bf16x3(groups, B // groups, K, ctypes.byref(n_out)) != 0:
+                raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into 128-row workgroups of at most four clouds")
+            t_out.value = 128
+            self._bf = net.w.bf16x3_packs()
+        elif _lib.lib().gp_pc_layout(self.model, int(tile), groups, B // groups, K, ctypes.byref(t_out), ctypes.byref(n_out)) != 0:
             raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                              "run the batches separately")
         if coupling_group is not None and (t_out.value & _lib.PLAN_HEADSPLIT):
@@ -61,9 +74,13 @@ class PCSampler:
         # the latency regime (three workgroups per 16-row tile, one head of the network each - GP_PLAN_HEADSPLIT)
         self.plan, self.nparts = t_out.value, n_out.value
         self.tile, self.hsplit = self.plan & ~_lib.PLAN_HEADSPLIT, (3 if self.plan & _lib.PLAN_HEADSPLIT else 1)
-        self.kernel_name = ("pc_step_kernel<16,0,split>" if self.hsplit == 3 else f"pc_step_kernel<{self.tile}>" if self.model == 0
-                            else f"pc_step_kernel<{self.tile},energy>") if self.tile in (16, 32, 64) else \
-            ("pc_step_chain_kernel<2>" if self.model == 0 else "pc_step_chain_kernel<2,energy>")
+        if precision == "bf16x3":
+            self.kernel_name = "pc_step_bf16x3_kernel"
+        elif self.tile in (16, 32, 64):
+            self.kernel_name = ("pc_step_kernel<16,0,split>" if self.hsplit == 3 else f"pc_step_kernel<{self.tile}>" if self.model == 0
+                                else f"pc_step_kernel<{self.tile},energy>")
+        else:
+            self.kernel_name = "pc_step_chain_kernel<2>" if self.model == 0 else "pc_step_chain_kernel<2,energy>"
         ts, sched = pc_schedule(num_steps)
         self.sched = sched.to(self.dev)
         self.tvec_all = net.time_embed(ts.to(self.dev))
@@ -87,6 +104,13 @@ class PCSampler:
 
     def launch_step(self, i):
         """Launch i of the chain (0 <= i <= n) on the current stream: finishes step i-1 and, for i < n, evaluates the score at t_i."""
+        if self.precision == "bf16x3":
+            t = self.net.w.tensors
+            _lib.call("gp_pc_step_bf16x3", self.groups, self.B // self.groups, self.K, i, self.n, ptr(self.cvec), ptr(self.tvec_all), ptr(self.sched),
+                      ptr(self.z1), ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials), ptr(self.traj),
+                      ptr(self._bf[0]), ptr(self._bf[1]), ptr(self._bf[2]), ptr(t["b_pose0"]), ptr(t["b_pose2"]), ptr(t["w_out"]), ptr(t["b_out"]),
+                      stream_ptr())
+            return
         _lib.call("gp_pc_step_plan", self.model, self.plan, self.groups, self.B // self.groups, self.K, i, self.n, self.net.w.ref(), ptr(self.cvec), ptr(self.tvec_all),
                   ptr(self.sched), ptr(self.z1), ptr(self.z2), ptr(self.centre), ptr(self.x), ptr(self.mean_x), ptr(self.score), ptr(self.partials),
                   ptr(self.traj), ptr(self.gn_ext), self.gn_rows, stream_ptr())

@@ -123,11 +123,12 @@ class SAScale:
         return self._bf16x3
 
 
-def pack_bf16x3(W, n_chunks, k_blocks):
+def pack_bf16x3(W, n_chunks, k_blocks, chain=True):
     """W [n_out, k_in] f32 -> int16 [k_blocks][n_chunks][2 = hi, lo][64 lanes][8]: the A / B operand fragments of
     v_mfma_f32_16x16x32_bf16 for output chunk nc (16 outputs) and k-block kb (32 inputs), lane l = (n = l % 16, g = l // 16), element e:
     input channel 32 kb + (4 g + e if e < 4 else 16 + 4 g + e - 4) - two consecutive D fragments of the previous layer, as the register
-    chain of csrc/sa_bf16x3.hip holds them.  Out-of-range outputs / inputs are zero."""
+    chain of csrc/sa_bf16x3.hip holds them (chain=False: the natural order 32 kb + 8 g + e, for a layer whose input is not a D fragment).
+    Out-of-range outputs / inputs are zero."""
     W = W.detach().float().cpu()
     n_out, k_in = W.shape
     Wp = torch.zeros(16 * n_chunks, 32 * k_blocks)
@@ -137,7 +138,10 @@ def pack_bf16x3(W, n_chunks, k_blocks):
     lanes = torch.arange(64)
     n, g = lanes % 16, lanes // 16
     e = torch.arange(8)
-    koff = torch.where(e < 4, 4 * g[:, None] + e[None, :], 16 + 4 * g[:, None] + (e[None, :] - 4))  # [64, 8]
+    if chain:
+        koff = torch.where(e < 4, 4 * g[:, None] + e[None, :], 16 + 4 * g[:, None] + (e[None, :] - 4))  # [64, 8]
+    else:
+        koff = 8 * g[:, None] + e[None, :]
     out = torch.empty(k_blocks, n_chunks, 2, 64, 8, dtype=torch.int16)
     for kb in range(k_blocks):
         for nc in range(n_chunks):
@@ -200,6 +204,18 @@ class ScoreNetWeights:
         t["w_pose0_t"] = pack_weight(g("pose_encoder.0.weight").t().contiguous())
         self.tensors = {k: v.to(device) for k, v in t.items()}
         self.struct = _lib.GpScoreNet(**{k: v.data_ptr() for k, v in self.tensors.items()})
+        self._raw = {"pose0": g("pose_encoder.0.weight"), "pose2": g("pose_encoder.2.weight"), "headx": W1[:, 1152:1408].contiguous()}
+        self._device = device
+        self._bf16x3 = None
+
+    def bf16x3_packs(self):
+        """Operands of the opt-in split-bf16 PC step (csrc/trunk_bf16x3.hip): the three dense layers of the trunk as hi / lo bf16 pairs in
+        the fragment order of v_mfma_f32_16x16x32_bf16 (pack_bf16x3) -> (w_pose0 [1][16][2][64][8], w_pose2 [8][16]..., w_headx [8][48]...)."""
+        if self._bf16x3 is None:
+            r = self._raw
+            self._bf16x3 = (pack_bf16x3(r["pose0"], 16, 1, chain=False).to(self._device), pack_bf16x3(r["pose2"], 16, 8).to(self._device),
+                            pack_bf16x3(r["headx"], 48, 8).to(self._device))
+        return self._bf16x3
 
     def ref(self):
         return ctypes.byref(self.struct)

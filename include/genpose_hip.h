@@ -273,6 +273,19 @@ int gp_pc_step_grouped(int ngroups, int nclouds_per_group, int k, int step, int 
                        const float *tvec_all, const float *sched, const float *z_langevin, const float *z_predictor,
                        const float *centre, float *x, float *mean_x, float *score, float *partials, float *traj, gp_stream_t s);
 
+/* OPT-IN, EXPLORATORY (round 5; csrc/trunk_bf16x3.hip): one launch of the PC sampler - gp_pc_step_grouped's contract (step = 0 .. nsteps, per-group
+ * batch-mean coupling, the same buffers) - with the score network's three dense layers on the BF16 matrix pipe as three-term split products
+ * (a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo, fp32 accumulate).  128 rows per workgroup (k >= 43: a workgroup's rows span at most four clouds;
+ * rows per group a multiple of 128 when ngroups > 1), one partial sum per wave: partials [nsteps][*nparts_out of gp_pc_layout_bf16x3].
+ * w_*_split: hi / lo bf16 pairs in the fragment order of v_mfma_f32_16x16x32_bf16 (genpose_amd/weights.py: pack_bf16x3 - pose_encoder.0
+ * [1][16][2][64][8] in natural k order, pose_encoder.2 [8][16]..., stacked heads [8][48]... in the register chain's k order); b_*, w_out [9][256],
+ * b_out [9] fp32.  PC sampler of the score model only (the RK45 driver and every default path keep the fp32 trunk). */
+int gp_pc_layout_bf16x3(int ngroups, int nclouds_per_group, int k, int *nparts_out);
+int gp_pc_step_bf16x3(int ngroups, int nclouds_per_group, int k, int step, int nsteps, const float *cvec, const float *tvec_all, const float *sched,
+                      const float *z_langevin, const float *z_predictor, const float *centre, float *x, float *mean_x, float *score, float *partials,
+                      float *traj, const void *w_pose0_split, const void *w_pose2_split, const void *w_headx_split, const float *b_pose0, const float *b_pose2,
+                      const float *w_out, const float *b_out, gp_stream_t s);
+
 /* Launch plan of the PC sampler for (ngroups x nclouds_per_group clouds x k candidates) and a model (see gp_pc_step_plan): tile = 0 asks for the automatic choice, else
  * 16 / 32 / 64 / 128 as in gp_score_eval_plan.  *tile_out = the plan taken, *nparts_out = partial sums of |score| per step
  * (`partials` must hold nsteps * nparts floats: one per workgroup in the tile form, one per wave in the chain form).  GP_EINVAL when a

@@ -82,3 +82,55 @@ def test_bf16x3_through_the_agent_is_opt_in():
     with pytest.raises(ValueError):
         from genpose_amd.encoder import Pointnet2EncoderHIP
         Pointnet2EncoderHIP(sd, "cuda", precision="fp8")
+
+
+def test_split_bf16_pc_step_against_fp32_and_oracle():
+    """The OPT-IN split-bf16 form of the PC sampler's score network (csrc/trunk_bf16x3.hip, PCSampler(precision='bf16x3')): the first score
+    evaluation against the fp32 kernels and against an fp64 evaluation of the network (stated bound: 3e-5 of the score's scale; the fp32
+    kernels: ~1e-6), a 30-step chain against the fp32 sampler and the oracle with the same draws, several batches per launch each with
+    its own coupling, a ragged last workgroup, replays to the same bits."""
+    from genpose_amd.samplers import PCSampler
+    from genpose_amd.scorenet import ScoreNetHIP
+    sd = go.make_state_dict(0, "score")
+    net = ScoreNetHIP(sd, "cuda")
+    n = 30
+    for B, K, groups in ((5, 50, 1), (64, 50, 2), (3, 43, 1)):
+        g = torch.Generator().manual_seed(B)
+        feat = torch.randn(B, 1024, generator=g) * 0.5
+        centre = torch.randn(B, 3, generator=g) * 0.1
+        x0 = torch.randn(B * K, 9, generator=g) * 50.0
+        z1, z2 = torch.randn(n, B * K, 9, generator=g), torch.randn(n, B * K, 9, generator=g)
+        cvec = net.cloud_embed(feat.cuda())
+        out = {}
+        for prec in ("f32", "bf16x3"):
+            smp = PCSampler(net, B, K, n, "cuda", groups=groups, precision=prec)
+            smp.cvec.copy_(cvec), smp.centre.copy_(centre.cuda()), smp.x.copy_(x0.cuda()), smp.z1.copy_(z1.cuda()), smp.z2.copy_(z2.cuda())
+            smp.launch_step(0)
+            torch.cuda.synchronize()
+            first = smp.score.clone()
+            mean_x = smp.run(cvec, centre.cuda(), x0.cuda(), z1.cuda(), z2.cuda())[1].clone()
+            again = smp.run(cvec, centre.cuda(), x0.cuda(), z1.cuda(), z2.cuda())[1]
+            assert torch.equal(again, mean_x)
+            out[prec] = (first, mean_x)
+            assert smp.kernel_name == ("pc_step_bf16x3_kernel" if prec == "bf16x3" else smp.kernel_name)
+        # first evaluation vs fp64
+        sd64 = {k: v.double() for k, v in sd.items()}
+        feat_r = feat.repeat_interleave(K, 0).double()
+        ref = go.score_forward(sd64, feat_r, x0.double(), torch.ones(B * K, 1, dtype=torch.float64))
+        scale = float(ref.abs().max())
+        e32 = float((out["f32"][0].double().cpu() - ref).abs().max()) / scale
+        ebf = float((out["bf16x3"][0].double().cpu() - ref).abs().max()) / scale
+        print(f"B={B} K={K} groups={groups}: first score evaluation vs fp64, max error / scale: fp32 {e32:.2e}, split bf16 {ebf:.2e}")
+        assert e32 < 5e-6 and ebf < GATE, (e32, ebf)
+        # the chain: fp32 sampler and oracle (same draws)
+        sc = float(out["f32"][1].abs().max())
+        np.testing.assert_allclose(out["bf16x3"][1].cpu().numpy(), out["f32"][1].cpu().numpy(), rtol=0, atol=1e-3 * sc)
+        if groups == 1:
+            cen_r = centre.repeat_interleave(K, 0)
+            fr = feat.repeat_interleave(K, 0)
+            _, oref = go.pc_sampler(lambda x, t: go.score_forward(sd, fr, x, t), x0, cen_r, n, z1, z2)
+            np.testing.assert_allclose(out["bf16x3"][1].cpu().numpy(), oref.numpy(), rtol=0, atol=1e-3 * float(oref.abs().max()))
+    with pytest.raises(NotImplementedError):
+        PCSampler(net, 5, 50, 4, "cuda", precision="bf16x3", model="energy")
+    with pytest.raises(ValueError):
+        PCSampler(net, 5, 10, 4, "cuda", precision="bf16x3")  # 10 candidates per cloud: a workgroup's 128 rows span 14 clouds
