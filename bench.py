@@ -281,7 +281,8 @@ def main():
             nfev = int(score_agent.net.last_sampler.last_stats["nfev"])
 
     if args.only_split_bf16:
-        print(json.dumps({"headline_f32": round(value, 2), "encoder_split_bf16": encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev))}), flush=True)
+        print(json.dumps({"headline_f32": round(value, 2), "encoder_split_bf16": split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev), False),
+                          "encoder_and_sampler_split_bf16": split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev), True)}), flush=True)
         return
     side = {}
     if rank == 0 and world == 1:
@@ -294,10 +295,11 @@ def main():
             side["drop_in_eval_single"] = drop_in_leg(torch, str(dev), K)
             side["config0_single_object"] = config0_leg(torch, str(dev))
             side["energy_model_pc_step"] = energy_model_leg(torch, str(dev), B, K, G)
-            try:  # an optional, exploratory leg must never cost the line
-                side["encoder_split_bf16"] = encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev))
-            except Exception as exc:  # noqa: BLE001
-                side["encoder_split_bf16"] = {"error": f"{type(exc).__name__}: {exc}"}
+            for name, too in (("encoder_split_bf16", False), ("encoder_and_sampler_split_bf16", True)):
+                try:  # optional, exploratory legs must never cost the line
+                    side[name] = split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev), too)
+                except Exception as exc:  # noqa: BLE001
+                    side[name] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
@@ -511,16 +513,18 @@ def one_batch_leg(torch, score_agent, pool, B, K, n):
             "rows_per_launch": B * K, "avg_launch_us": r["avg_launch_us"], "frac": r["frac"]}
 
 
-def encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, dev):
-    """OPT-IN, EXPLORATORY (round 5; csrc/sa_bf16x3.hip): the headline workload with grouping levels 1 and 2 of the encoder on the bf16
-    matrix pipe as three-term split products (a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo, fp32 accumulate).  A SEPARATE leg: the headline
-    `value` above is pure fp32.  Reported with its measured deviation: encoder features against the fp32 kernels' on the same clouds
-    (centres and neighbourhoods are bit-identical: they depend on coordinates only).  The sampler trunk stays on the fp32 pipe."""
+def split_bf16_leg(torch, score_agent, pool, B, K, n, G, dev, sampler_too):
+    """OPT-IN, EXPLORATORY (round 5; csrc/sa_bf16x3.hip, csrc/trunk_bf16x3.hip): the headline workload with dense layers on the bf16 matrix
+    pipe as three-term split products (a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo, fp32 accumulate) - grouping levels 1-2 of the encoder
+    (`encoder_precision`), and with `sampler_too` also the three dense layers of the PC sampler's score network (`sampler_precision`).
+    SEPARATE legs: the headline `value` above is pure fp32.  Reported with the measured deviation: encoder features against the fp32
+    kernels' on the same clouds, and - same prior and noise draws through both paths - the PC-100 poses against the fp32 path's."""
     from genpose_amd.config import get_config
     from genpose_amd.pipeline import PipelinedPCPredictor
     from genpose_amd.posenet_agent import PoseNet
     from genpose_amd.weights_synth import make_state_dict
-    agent = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=["pc"], sampling_steps=n, encoder_precision="bf16x3"))
+    agent = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=["pc"], sampling_steps=n, encoder_precision="bf16x3",
+                               sampler_precision="bf16x3" if sampler_too else "f32"))
     agent.load_state_dict(make_state_dict(0, "score"))
     pipe = PipelinedPCPredictor(agent, B, K, n, batches_per_launch=G, overlap=False)  # one stream, like the headline run
     batches = lambda count: [pool[j % len(pool)] for j in range(count)]
@@ -537,29 +541,48 @@ def encoder_split_bf16_leg(torch, score_agent, pool, B, K, n, G, dev):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     dt = statistics.median(times)
-    big = torch.cat(batches(G), dim=0)
-    f32 = score_agent.net.pts_encoder.forward(big).clone()
-    fbf = agent.net.pts_encoder.forward(big).clone()
-    scale = float(f32.abs().max())
-    d = (fbf - f32).abs()
-    reps = 10
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    for enc_, a, b in ((score_agent.net.pts_encoder, ev[0], ev[1]), (agent.net.pts_encoder, ev[2], ev[3])):
-        for _ in range(3):
-            enc_.encode(big)
-        a.record()
-        for _ in range(reps):
-            enc_.encode(big)
-        b.record()
-    torch.cuda.synchronize()
     in_situ = pipe.sampler_launch_seconds()
-    return {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "batches_per_launch": G,
-            "sampler_in_situ_avg_launch_us": round(in_situ * 1e6, 2) if in_situ else None,
-            "dtype": "f32 via 3 x bf16 split products, fp32 accumulate (encoder grouping levels 1-2); everything else f32",
-            "opt_in": "cfg.encoder_precision = 'bf16x3' (default 'f32')",
-            "encoder_pass_ms": {"clouds": int(big.shape[0]), "f32": round(ev[0].elapsed_time(ev[1]) / reps, 3), "bf16x3": round(ev[2].elapsed_time(ev[3]) / reps, 3)},
-            "feature_deviation_vs_f32": {"max_abs_over_scale": float(d.max()) / scale, "rms_over_scale": float(d.pow(2).mean().sqrt()) / scale,
-                                         "clouds": int(big.shape[0]), "note": "per-level error against fp64: tests/test_gpu_bf16x3.py, profiles/r5_bf16x3_gate.txt"}}
+    out = {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "batches_per_launch": G,
+           "sampler_kernel": pipe._sampler(0, G).kernel_name, "sampler_in_situ_avg_launch_us": round(in_situ * 1e6, 2) if in_situ else None,
+           "dtype": "f32 via 3 x bf16 split products, fp32 accumulate: encoder grouping levels 1-2" + (" and the PC sampler's score network" if sampler_too else "")
+                    + "; everything else f32",
+           "opt_in": "cfg.encoder_precision = 'bf16x3'" + (", cfg.sampler_precision = 'bf16x3'" if sampler_too else "") + " (defaults 'f32')"}
+    big = torch.cat(batches(G), dim=0)
+    if not sampler_too:
+        f32 = score_agent.net.pts_encoder.forward(big).clone()
+        fbf = agent.net.pts_encoder.forward(big).clone()
+        scale = float(f32.abs().max())
+        d = (fbf - f32).abs()
+        reps = 10
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for enc_, a, b in ((score_agent.net.pts_encoder, ev[0], ev[1]), (agent.net.pts_encoder, ev[2], ev[3])):
+            for _ in range(3):
+                enc_.encode(big)
+            a.record()
+            for _ in range(reps):
+                enc_.encode(big)
+            b.record()
+        torch.cuda.synchronize()
+        out["encoder_pass_ms"] = {"clouds": int(big.shape[0]), "f32": round(ev[0].elapsed_time(ev[1]) / reps, 3), "bf16x3": round(ev[2].elapsed_time(ev[3]) / reps, 3)}
+        out["feature_deviation_vs_f32"] = {"max_abs_over_scale": float(d.max()) / scale, "rms_over_scale": float(d.pow(2).mean().sqrt()) / scale,
+                                           "clouds": int(big.shape[0]), "note": "per-level error against fp64: tests/test_gpu_bf16x3.py, profiles/r5_bf16x3_gate.txt"}
+    else:
+        # the same draws through the fp32 path and this one: how far the PC-100 poses move
+        gen = torch.Generator().manual_seed(5)
+        R1 = B * K
+        priors = [torch.randn(R1, 9, generator=gen).to(dev) for _ in range(G)]
+        noises = [(torch.randn(n, R1, 9, generator=gen).to(dev), torch.randn(n, R1, 9, generator=gen).to(dev)) for _ in range(G)]
+        ref_pipe = PipelinedPCPredictor(score_agent, B, K, n, batches_per_launch=G, overlap=False)
+        ref = torch.stack([o.clone() for o in ref_pipe.run(batches(G), prior_noise=priors, noise=noises)])
+        got = torch.stack([o.clone() for o in pipe.run(batches(G), prior_noise=priors, noise=noises)])
+        torch.cuda.synchronize()
+        rot = (got[..., :6] - ref[..., :6]).abs().reshape(-1)
+        tr = (got[..., 6:] - ref[..., 6:]).abs().max() / ref[..., 6:].abs().max()
+        out["pose_deviation_vs_f32_same_draws"] = {"rotation_abs_p999": float(torch.quantile(rot[: 1 << 24].float(), 0.999)), "rotation_abs_max": float(rot.max()),
+                                                   "translation_max_over_scale": float(tr), "clouds": int(G * B),
+                                                   "note": "PC-100 tolerance between two fp32 plans of the same batch (tests/test_gpu_fullsize.py): rotation p99.9 1e-3, max 1e-2, "
+                                                           "translation 1e-4 of its scale; first score evaluation against fp64: tests/test_gpu_bf16x3.py"}
+    return out
 
 
 def ode_leg(torch, B, K, G, T0, pool, dev):

@@ -94,7 +94,7 @@ def test_split_bf16_pc_step_against_fp32_and_oracle():
     sd = go.make_state_dict(0, "score")
     net = ScoreNetHIP(sd, "cuda")
     n = 30
-    for B, K, groups in ((5, 50, 1), (64, 50, 2), (3, 43, 1)):
+    for B, K, groups in ((5, 50, 1), (128, 50, 2), (3, 43, 1)):
         g = torch.Generator().manual_seed(B)
         feat = torch.randn(B, 1024, generator=g) * 0.5
         centre = torch.randn(B, 3, generator=g) * 0.1
