@@ -578,10 +578,15 @@ def split_bf16_leg(torch, score_agent, pool, B, K, n, G, dev, sampler_too):
         torch.cuda.synchronize()
         rot = (got[..., :6] - ref[..., :6]).abs().reshape(-1)
         tr = (got[..., 6:] - ref[..., 6:]).abs().max() / ref[..., 6:].abs().max()
-        out["pose_deviation_vs_f32_same_draws"] = {"rotation_abs_p999": float(torch.quantile(rot[: 1 << 24].float(), 0.999)), "rotation_abs_max": float(rot.max()),
+        rq = torch.quantile(rot[: 1 << 24].float(), torch.tensor([0.5, 0.99, 0.999], device=rot.device))
+        out["pose_deviation_vs_f32_same_draws"] = {"rotation_abs_median": float(rq[0]), "rotation_abs_p99": float(rq[1]), "rotation_abs_p999": float(rq[2]),
+                                                   "rotation_abs_max": float(rot.max()),
                                                    "translation_max_over_scale": float(tr), "clouds": int(G * B),
-                                                   "note": "PC-100 tolerance between two fp32 plans of the same batch (tests/test_gpu_fullsize.py): rotation p99.9 1e-3, max 1e-2, "
-                                                           "translation 1e-4 of its scale; first score evaluation against fp64: tests/test_gpu_bf16x3.py"}
+                                                   "note": "the 100-step recursion renormalises the rotation columns every step and amplifies a perturbation for the rare row whose "
+                                                           "column passes near zero: two fp32 launch plans of one batch differ by p99.9 2.6e-5 / max 7e-3 "
+                                                           "(tests/test_gpu_fullsize.py), this arithmetic (8e-6 of the score's scale per evaluation against fp64, "
+                                                           "tests/test_gpu_bf16x3.py) by more - every draw is a valid sample of the same sampler, but NOT "
+                                                           "within the parity tolerance: opt-in only"}
     return out
 
 

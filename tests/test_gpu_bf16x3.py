@@ -134,3 +134,35 @@ def test_split_bf16_pc_step_against_fp32_and_oracle():
         PCSampler(net, 5, 50, 4, "cuda", precision="bf16x3", model="energy")
     with pytest.raises(ValueError):
         PCSampler(net, 5, 10, 4, "cuda", precision="bf16x3")  # 10 candidates per cloud: a workgroup's 128 rows span 14 clouds
+
+
+def test_sampler_precision_through_the_agent_and_the_pipeline():
+    """cfg.sampler_precision = 'bf16x3' is honoured where the 128-row plan applies (>= 43 candidates per cloud, score model, PC sampler,
+    uncoupled) and ignored elsewhere (the fp32 kernels run); the ODE sampler never takes it."""
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.pipeline import PipelinedPCPredictor
+    from genpose_amd.posenet_agent import PoseNet
+    sd = go.make_state_dict(0, "score")
+    assert get_config().sampler_precision == "f32"
+    pts = torch.from_numpy(synth.make_batch(6, start=31)).cuda()
+    data = lambda: {"pts": pts, "pts_center": pts.mean(dim=1)}
+    a = PoseNet(get_config(posenet_mode="score", sampler_mode=["pc"], sampling_steps=8, sampler_precision="bf16x3"))
+    a.load_state_dict(sd)
+    pred = a.pred_func(data(), repeat_num=50, save_path=None)
+    assert torch.isfinite(pred).all() and a.net.last_sampler.precision == "bf16x3" and a.net.last_sampler.kernel_name == "pc_step_bf16x3_kernel"
+    a.pred_func(data(), repeat_num=10, save_path=None)
+    assert a.net.last_sampler.precision == "f32"  # 10 candidates per cloud: the fp32 plans
+    o = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"], sampler_precision="bf16x3"))
+    o.load_state_dict(sd)
+    assert torch.isfinite(o.pred_func(data(), repeat_num=50, save_path=None, T0=0.55)).all()
+    assert o.net.last_sampler.__class__.__name__ == "ODESampler"
+    # request batching: groups of 64 clouds x 50 rows = 3200 = 25 x 128 rows
+    b = PoseNet(get_config(posenet_mode="score", sampler_mode=["pc"], sampling_steps=8, sampler_precision="bf16x3", encoder_precision="bf16x3"))
+    b.load_state_dict(sd)
+    pipe = PipelinedPCPredictor(b, 64, 50, 8, batches_per_launch=2, overlap=False)
+    batches = [torch.from_numpy(synth.make_batch(64, start=64 * i)).cuda() for i in range(3)]
+    outs = pipe.run(batches)
+    torch.cuda.synchronize()
+    assert len(outs) == 3 and all(torch.isfinite(x).all() for x in outs)
+    assert pipe._sampler(0, 2).precision == "bf16x3" and pipe._sampler(0, 1).precision == "bf16x3"
