@@ -20,7 +20,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n
 t_enc = timeit(lambda: enc.forward(pts))
 feat = enc.forward(pts); cvec = net.cloud_embed(feat)
-smp = PCSampler(net, B, K, 100, "cuda", use_graph=True)
+smp = PCSampler(net, B, K, 100, "cuda", use_graph=True, precision=os.environ.get("GP_SMP_PRECISION", "f32"))
 x0 = torch.randn(B * K, 9, device="cuda") * 50
 t_pc = timeit(lambda: smp.run(cvec, pts.mean(1), x0), 5)
 print(f"B={B} K={K} ({smp.kernel_name}): encoder {t_enc:.3f} ms ({B*2.201/t_enc:.1f} TFLOP/s), "

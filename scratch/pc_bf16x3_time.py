@@ -20,4 +20,5 @@ for G in (1, 2, 5, 10, 20, 40):
         us = e0.elapsed_time(e1) / 10 / (n + 1) * 1e3
         row.append((smp.kernel_name, us))
     R = G * B1 * K
-    print(f"{R:6d} rows: {row[0][0]:28s} {row[0][1]:7.1f} us ({R * 0.5335 / row[0][1] / 1e0 / 1e6 * 1e6 / 1e6:.1f} TFLOP/s)   {row[1][0]} {row[1][1]:7.1f} us ({R * 0.5335e6 / row[1][1] / 1e6:.1f} TFLOP/s of fp32-equivalent work)   {row[0][1] / row[1][1]:.2f}x")
+    tf = lambda us: R * 0.5335e6 / us / 1e6
+    print(f"{R:6d} rows: {row[0][0]:26s} {row[0][1]:7.1f} us ({tf(row[0][1]):6.1f} TFLOP/s)   {row[1][0]} {row[1][1]:7.1f} us ({tf(row[1][1]):6.1f} TFLOP/s of fp32-equivalent work)   {row[0][1] / row[1][1]:.2f}x")

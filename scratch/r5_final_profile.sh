@@ -21,6 +21,7 @@ echo "== GP_BENCH_ONE_DEVICE=1 bench.py --gpus 8 --no-cpu-baseline --no-secondar
 timeout 300 python scratch/bench_tracking.py 16 64 128 > $O/tracking.txt 2>/dev/null
 timeout 300 python scratch/headsplit_plans.py > $O/plans.txt 2>&1
 timeout 200 python scratch/bf16x3_gate.py > $O/bf16x3_gate.txt 2>&1
+timeout 200 python scratch/pc_bf16x3_time.py > $O/pc_bf16x3_plans.txt 2>&1
 for mode in forward graph; do for B in 5 64 320 640; do timeout 100 python scratch/enc_profile.py $B 30 $mode 2>/dev/null | tail -1; done; done > $O/encoder_wall.txt
 for B in 320 640; do timeout 100 python scratch/enc_profile.py $B 30 graph bf16x3 2>/dev/null | tail -1; done >> $O/encoder_wall.txt
 bash scratch/enc_kernel_stats.sh 320 $O/encoder320_kernel_stats.txt > /dev/null 2>&1
@@ -44,10 +45,12 @@ for B in 64 640; do
 done
 timeout 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace -d /tmp/pmc_sq_640 -o run -- python scratch/microbench.py 640 50 > $O/pmc_sq_640.log 2>&1
 GP_ENC_PRECISION=bf16x3 timeout 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace -d /tmp/pmc_sq_bf -o run -- python scratch/microbench.py 640 50 > $O/pmc_sq_bf.log 2>&1
+GP_SMP_PRECISION=bf16x3 timeout 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace -d /tmp/pmc_sq_bfpc -o run -- python scratch/microbench.py 640 50 > $O/pmc_sq_bfpc.log 2>&1
 F64=$(find /tmp/pmc_fetch_64 -name "*.db" | head -1); W64=$(find /tmp/pmc_write_64 -name "*.db" | head -1)
 F640=$(find /tmp/pmc_fetch_640 -name "*.db" | head -1); W640=$(find /tmp/pmc_write_640 -name "*.db" | head -1)
 python scratch/pmc_traffic.py $O/pmc_traffic.json 64:$F64:$W64 640:$F640:$W640 > $O/pmc_traffic.log 2>&1; tail -12 $O/pmc_traffic.log
 python scratch/pmc_summary.py $(find /tmp/pmc_sq_640 -name "*.db" | head -1) > $O/pmc_sq_summary.txt 2>&1
 echo "---- encoder precision bf16x3 (opt-in): the split-bf16 kernels" >> $O/pmc_sq_summary.txt
-python scratch/pmc_summary.py $(find /tmp/pmc_sq_bf -name "*.db" | head -1) bf16x3 >> $O/pmc_sq_summary.txt 2>&1; head -12 $O/pmc_sq_summary.txt
+python scratch/pmc_summary.py $(find /tmp/pmc_sq_bf -name "*.db" | head -1) bf16x3 >> $O/pmc_sq_summary.txt 2>&1
+python scratch/pmc_summary.py $(find /tmp/pmc_sq_bfpc -name "*.db" | head -1) pc_step_bf16x3 >> $O/pmc_sq_summary.txt 2>&1; head -12 $O/pmc_sq_summary.txt
 ls $O
