@@ -21,6 +21,7 @@ from .sde import SIGMA_MAX, SIGMA_MIN
 
 class GFObjectPose:
     MAX_SAMPLERS = 8  # distinct (sampler, B, K, steps ...) geometries kept alive
+    BF16X3_MIN_ROWS = 9600  # opt-in split-bf16 PC step: launches from here on (profiles/r5_pc_bf16x3_plans.txt: 6 400 rows 47 vs 39 us, 16 000 rows 48 vs 71)
 
     def __init__(self, cfg, prior_fn, marginal_prob_fn, sde_fn, sampling_eps, T):
         self.cfg = cfg
@@ -118,6 +119,8 @@ class GFObjectPose:
         """cfg.sampler_precision = 'bf16x3' (opt-in, exploratory): the PC sampler's score network on split-bf16 products where the 128-row
         launch plan applies (>= 43 candidates per cloud, uncoupled); anything else keeps the fp32 kernels."""
         if getattr(self.cfg, "sampler_precision", "f32") != "bf16x3" or coupling is not None or K < 43:
+            return "f32"
+        if B * K < self.BF16X3_MIN_ROWS:  # a round of its 128-row workgroups costs ~47 us whatever the fill: below, the fp32 plans are faster
             return "f32"
         return "bf16x3" if groups == 1 or ((B // groups) * K) % 128 == 0 else "f32"
 

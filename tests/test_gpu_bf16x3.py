@@ -145,17 +145,19 @@ def test_sampler_precision_through_the_agent_and_the_pipeline():
     from genpose_amd.posenet_agent import PoseNet
     sd = go.make_state_dict(0, "score")
     assert get_config().sampler_precision == "f32"
-    pts = torch.from_numpy(synth.make_batch(6, start=31)).cuda()
-    data = lambda: {"pts": pts, "pts_center": pts.mean(dim=1)}
+    pts = torch.from_numpy(synth.make_batch(200, start=31)).cuda()
+    data = lambda n=200: {"pts": pts[:n].contiguous(), "pts_center": pts[:n].mean(dim=1)}
     a = PoseNet(get_config(posenet_mode="score", sampler_mode=["pc"], sampling_steps=8, sampler_precision="bf16x3"))
     a.load_state_dict(sd)
-    pred = a.pred_func(data(), repeat_num=50, save_path=None)
+    pred = a.pred_func(data(), repeat_num=50, save_path=None)  # 10 000 rows
     assert torch.isfinite(pred).all() and a.net.last_sampler.precision == "bf16x3" and a.net.last_sampler.kernel_name == "pc_step_bf16x3_kernel"
     a.pred_func(data(), repeat_num=10, save_path=None)
     assert a.net.last_sampler.precision == "f32"  # 10 candidates per cloud: the fp32 plans
+    a.pred_func(data(6), repeat_num=50, save_path=None)
+    assert a.net.last_sampler.precision == "f32" and a.net.last_sampler.hsplit == 3  # 300 rows: the latency regime's fp32 plan is faster
     o = PoseNet(get_config(posenet_mode="score", sampler_mode=["ode"], sampler_precision="bf16x3"))
     o.load_state_dict(sd)
-    assert torch.isfinite(o.pred_func(data(), repeat_num=50, save_path=None, T0=0.55)).all()
+    assert torch.isfinite(o.pred_func(data(6), repeat_num=50, save_path=None, T0=0.55)).all()
     assert o.net.last_sampler.__class__.__name__ == "ODESampler"
     # request batching: groups of 64 clouds x 50 rows = 3200 = 25 x 128 rows
     b = PoseNet(get_config(posenet_mode="score", sampler_mode=["pc"], sampling_steps=8, sampler_precision="bf16x3", encoder_precision="bf16x3"))
@@ -165,4 +167,8 @@ def test_sampler_precision_through_the_agent_and_the_pipeline():
     outs = pipe.run(batches)
     torch.cuda.synchronize()
     assert len(outs) == 3 and all(torch.isfinite(x).all() for x in outs)
-    assert pipe._sampler(0, 2).precision == "bf16x3" and pipe._sampler(0, 1).precision == "bf16x3"
+    assert pipe._sampler(0, 2).precision == "f32"  # 6 400 rows per launch: below the threshold
+    pipe4 = PipelinedPCPredictor(b, 64, 50, 8, batches_per_launch=4, overlap=False)  # 12 800 rows per launch
+    outs4 = pipe4.run(batches + batches[:1])
+    torch.cuda.synchronize()
+    assert len(outs4) == 4 and pipe4._sampler(0, 4).precision == "bf16x3"
