@@ -56,28 +56,39 @@ __device__ __forceinline__ uint32_t fkey(float f) {
 }
 
 // Wave-wide max of a u32 with DPP row operations (VALU speed; no LDS crossbar traffic): quad swaps, row mirrors, then
-// row_bcast15 / row_bcast31 accumulate into lane 63, which is read back as a wave-uniform scalar.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
-    return o > v ? o : v;
-}
+// row_bcast15 / row_bcast31 accumulate into lane 63, which is read back as a wave-uniform scalar.  Written as six `v_max_u32_dpp`
+// (the compiler's form of update_dpp + max is mov / nop / mov_dpp / max: four issue slots per step, and every slot of this chain is
+// on the critical path of a pick); a VALU result needs two wait states before a DPP read, hence the s_nop 1 in front of each step.
+// All 64 lanes must be active.
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    v = dpp_max_u32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v = dpp_max_u32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v = dpp_max_u32<0x141, 0xF>(v);  // row_half_mirror
-    v = dpp_max_u32<0x140, 0xF>(v);  // row_mirror -> every lane of a 16-lane row holds the row max
-    v = dpp_max_u32<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
-    v = dpp_max_u32<0x143, 0xC>(v);  // row_bcast31 into rows 2,3 -> lane 63 holds the wave max
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"   // every lane of a 16-lane row holds the row max
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // into rows 1, 3 (other rows keep their value)
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // into rows 2, 3 -> lane 63 holds the wave max
+        "s_nop 1"
+        : "+v"(v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// Wave-wide max of the packed FPS key (hi = distance key, lo = tie rank) in two 32-bit passes:
-// max distance first, then the max rank among the lanes that hold it.
-__device__ __forceinline__ unsigned long long wave_max_key(uint32_t dkey, uint32_t rank) {
-    const uint32_t m = wave_max_u32(dkey);
-    const uint32_t r = wave_max_u32(dkey == m ? rank : 0u);
-    return ((unsigned long long)m << 32) | r;
+// max of two (distance bits, rank) keys held as hi:lo of a register pair, in ONE instruction: for 0 <= hi < 0x7ff00000 the pair read as a
+// double is a non-negative finite number (or a subnormal / zero: fp64 subnormals are never flushed on this target), and for those the order of
+// the doubles is the order of the 64-bit patterns - v_max_f64 is the 64-bit unsigned max the ISA lacks.  hi is a running minimum that starts
+// at 1e10f (0x501502f9) or at the caller's temp (finite, >= 0), so the exponent field never reaches 0x7ff.  Inline asm: as llvm.maxnum the
+// compiler would first canonicalise both operands (IEEE mode), doubling the work.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));  // .x = lo (rank), .y = hi (distance bits): one 64-bit register pair
+__device__ __forceinline__ u32x2 max_key(u32x2 a, u32x2 b) {
+    u32x2 r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // LDS-qualified pointers: with plain `const float *` the planes travel through a pointer array and the winner's coordinates are
@@ -87,8 +98,9 @@ typedef const lds_f32 *lds_cptr;
 template <typename T>
 __device__ __forceinline__ lds_cptr as_lds(const T *p) { return (lds_cptr)(p); }
 
-constexpr int FPS_T = 256;       // threads per cloud
-constexpr int FPS_MAXPPT = 16;   // register-resident points per thread (n <= 4096)
+constexpr int FPS_T = 256;       // threads per cloud of the wide form (n > 1024, and the global-memory fallback)
+constexpr int FPS_W = 64;        // ... of the one-wave form (n <= 1024): no cross-wave exchange, no barrier in the pick loop
+constexpr int FPS_MAXPPT = 16;   // register-resident points per thread (n <= 1024 on one wave, n <= 4096 on four)
 
 struct FpsRank {
     int S, logS, Q;
@@ -123,33 +135,41 @@ __device__ __forceinline__ FpsRank make_rank(int n) {
     return r;
 }
 
-// One FPS pass over the n points held in LDS (sx/sy/sz) selecting m of them.
+// One FPS pass over the n points held in LDS (sx/sy/sz) selecting m of them, by T threads (T / 64 waves) with PPT points each in registers.
 // temp_io: optional global running-min buffer (API semantics) - read at start, written back at the end.
-template <int AR, int PPT, bool FULL = false>  // FULL: n == PPT * FPS_T exactly (no bounds checks in the hot loop)
+//
+// A pick is one dependent chain, so its length in issue slots is the kernel's run time.  Per pick: the winner's coordinates (LDS), the
+// distance update (packed f32, two points per instruction), the running minimum (v_min_u32 on the bit patterns), the thread's best
+// (distance, rank) pair (one v_max_f64 per point: max_key), the wave's largest distance (six DPP steps), then the tie rule - the largest
+// RANK among the lanes that hold that distance (six more DPP steps).  T == 64: the wave's result is the cloud's, in scalar registers, and the next pick
+// starts at once; T > 64: one 64-bit LDS slot per wave, one barrier.
+// Measured at 320 clouds of 1024 -> 512 -> 128 (round 5, profiles/r5_fps_waves.txt): the round-4 form (four waves x 4 points, compiler-
+// scheduled reductions, per-point (distance, rank) tracking) 414 us; this pass on four / two / one wave(s): 271 / 279 / 246 us (5 clouds: 230
+// either way - the exchange through LDS and the barrier cost what the extra points per lane cost).  One wave ships for n <= 1024.
+template <int AR, int PPT, int T, bool FULL = false>  // FULL: n == PPT * T exactly (no bounds checks when the points are loaded)
 __device__ void fps_pass(int n, int m, lds_cptr sx, lds_cptr sy, lds_cptr sz, float *temp_io,
                          int32_t *idx_out, unsigned long long (*slots)[FPS_T / 64]) {
     const int tid = threadIdx.x;
     const FpsRank rk = make_rank(n);
-    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
-    uint32_t rnk[PPT];
+    float px[PPT], py[PPT], pz[PPT];
+    u32x2 pt[PPT];  // per point: {rank (fixed), bits of the running minimum}: the 64-bit key of max_key, kept as a register pair
+    // points past the end: running minimum +0 and rank 0 - min(d, 0) stays 0, so they are never ahead of a real point and the loop
+    // needs no bounds checks (squared distances are >= +0 for finite clouds, where the unsigned order of the bits IS the float order)
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        int k = tid + j * FPS_T;
-        bool ok = k < n;
+        int k = tid + j * T;
+        bool ok = FULL || k < n;
         px[j] = ok ? sx[k] : 0.f;
         py[j] = ok ? sy[k] : 0.f;
         pz[j] = ok ? sz[k] : 0.f;
-        tmp[j] = ok ? (temp_io ? temp_io[k] : 1e10f) : 0.f;
-        rnk[j] = ok ? rk.rank(k) : 0u;
+        pt[j].y = __float_as_uint(ok ? (temp_io ? temp_io[k] : 1e10f) : 0.f);
+        pt[j].x = ok ? rk.rank(k) : 0u;
     }
     int old = 0;
-    if (tid == 0) idx_out[0] = 0;
+    [[maybe_unused]] int mine = 0;  // T == 64: lane (it % 64) keeps pick it; flushed to idx_out every 64 picks
+    if (T > 64 && tid == 0) idx_out[0] = 0;
     for (int it = 1; it < m; ++it) {
         float x1 = sx[old], y1 = sy[old], z1 = sz[old];
-        // thread-local best (distance bits, rank).  Squared distances and the running minimum are >= +0 (finite clouds: never NaN), where the
-        // unsigned order of the bit patterns IS the float order: the loop compares raw bits, and the order-preserving key of fkey() - for
-        // non-negative floats just the sign bit set - is applied once, to the thread's winner (valid keys are >= 0x80000000)
-        uint32_t bd = 0u, br = 0u;
         float dist[PPT];
         if constexpr (PPT % 2 == 0) {
             // two points per instruction on the packed-f32 VALU (the same IEEE operations, in the same order, as sqdist<AR>)
@@ -164,38 +184,56 @@ __device__ void fps_pass(int n, int m, lds_cptr sx, lds_cptr sy, lds_cptr sz, fl
 #pragma unroll
             for (int j = 0; j < PPT; ++j) dist[j] = sqdist<AR>(px[j], py[j], pz[j], x1, y1, z1);
         }
+        // fminf(d, tmp) on the bit patterns (one v_min_u32 instead of canonicalise + v_min_f32), then the thread's best (distance, rank) pair:
+        // lexicographic max of PPT 64-bit keys, PPT - 1 instructions (max_key)
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            int k = tid + j * FPS_T;
-            if (FULL || k < n) {
-                // fminf(d, tmp) on the bit patterns: one v_min_u32 instead of canonicalise + v_min_f32
-                const uint32_t du = __float_as_uint(dist[j]), tu = __float_as_uint(tmp[j]);
-                const uint32_t dk = du < tu ? du : tu;
-                tmp[j] = __uint_as_float(dk);
-                const bool better = dk > bd || (dk == bd && rnk[j] > br);
-                bd = better ? dk : bd;
-                br = better ? rnk[j] : br;
-            }
+            const uint32_t du = __float_as_uint(dist[j]), tu = pt[j].y;
+            pt[j].y = du < tu ? du : tu;  // (written straight into the high half of the point's pair)
         }
-        bd |= 0x80000000u;
-        const unsigned long long best = wave_max_key(bd, br);
-        const int par = it & 1;
-        if ((tid & 63) == 0) slots[par][tid >> 6] = best;
-        __syncthreads();
-        unsigned long long v = slots[par][0];
+        u32x2 key[PPT];
 #pragma unroll
-        for (int w = 1; w < FPS_T / 64; ++w) {
-            unsigned long long o = slots[par][w];
-            v = o > v ? o : v;
+        for (int j = 0; j < PPT; ++j) key[j] = pt[j];
+#pragma unroll
+        for (int st = 1; st < PPT; st <<= 1)
+#pragma unroll
+            for (int j = 0; j + st < PPT; j += 2 * st) key[j] = max_key(key[j], key[j + st]);
+        const uint32_t bd = key[0].y, br = key[0].x;
+        // the wave's: largest distance, then the largest rank among the lanes that hold it
+        const uint32_t wm = wave_max_u32(bd);
+        const uint32_t cr = bd == wm ? br : 0u;
+        const uint32_t wr = wave_max_u32(cr);
+        if constexpr (T == 64) {
+            old = rk.unrank(wr);
+            if ((it & 63) == 0) {  // picks it-64 .. it-1 are complete (pick 0 is point 0: `mine` starts at 0)
+                idx_out[it - 64 + tid] = mine;
+            }
+            mine = tid == (it & 63) ? old : mine;
+        } else {
+            const int par = it & 1;
+            if ((tid & 63) == 0) slots[par][tid >> 6] = ((unsigned long long)wm << 32) | wr;
+            __syncthreads();
+            unsigned long long v = slots[par][0];
+#pragma unroll
+            for (int w = 1; w < T / 64; ++w) {
+                unsigned long long o = slots[par][w];
+                v = o > v ? o : v;
+            }
+            old = rk.unrank((uint32_t)(v & 0xffffffffull));
+            if (tid == 0) idx_out[it] = old;
         }
-        old = rk.unrank((uint32_t)(v & 0xffffffffull));
-        if (tid == 0) idx_out[it] = old;
+    }
+    if constexpr (T == 64) {
+        if (m > 0) {
+            const int base = (m - 1) & ~63;
+            if (base + tid < m) idx_out[base + tid] = mine;
+        }
     }
     if (temp_io) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            int k = tid + j * FPS_T;
-            if (k < n) temp_io[k] = tmp[j];
+            int k = tid + j * T;
+            if (k < n) temp_io[k] = __uint_as_float(pt[j].y);
         }
     }
 }
@@ -220,9 +258,10 @@ __device__ void fps_pass_big(int n, int m, const float *xyz, float *temp, int32_
             bd = better ? dk : bd;
             br = better ? rr : br;
         }
-        const unsigned long long best = wave_max_key(bd, br);
+        const uint32_t wm = wave_max_u32(bd);
+        const uint32_t wr = wave_max_u32(bd == wm ? br : 0u);
         const int par = it & 1;
-        if ((tid & 63) == 0) slots[par][tid >> 6] = best;
+        if ((tid & 63) == 0) slots[par][tid >> 6] = ((unsigned long long)wm << 32) | wr;
         __syncthreads();
         unsigned long long v = slots[par][0];
 #pragma unroll
@@ -235,9 +274,9 @@ __device__ void fps_pass_big(int n, int m, const float *xyz, float *temp, int32_
     }
 }
 
-template <int AR, int PPT>
-__global__ __launch_bounds__(FPS_T) void fps_kernel(int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
-                                                    int32_t *__restrict__ idx) {
+template <int AR, int PPT, int T>
+__global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__restrict__ xyz, float *__restrict__ temp,
+                                                int32_t *__restrict__ idx) {
     extern __shared__ float lds[];  // sx[n] sy[n] sz[n]
     __shared__ unsigned long long slots[2][FPS_T / 64];
     const int b = blockIdx.x;
@@ -245,13 +284,13 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(int n, int m, const float *_
     temp += (size_t)b * n;
     idx += (size_t)b * m;
     float *sx = lds, *sy = lds + n, *sz = lds + 2 * n;
-    for (int i = threadIdx.x; i < n * 3; i += FPS_T) {
+    for (int i = threadIdx.x; i < n * 3; i += T) {
         float v = xyz[i];
         int k = i / 3, c = i - k * 3;
         (c == 0 ? sx : c == 1 ? sy : sz)[k] = v;
     }
     __syncthreads();
-    fps_pass<AR, PPT>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), temp, idx, slots);
+    fps_pass<AR, PPT, T>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), temp, idx, slots);
 }
 
 template <int AR>
@@ -271,11 +310,30 @@ struct FpsChainArgs {
     float *new_xyz[3];
 };
 
+// one level of the chain with the widest register-resident form that fits: n <= PPT * T
+template <int AR, int T, int PPT>
+__device__ __forceinline__ void fps_level(int n, int m, const float *sx, const float *sy, const float *sz, int32_t *sel,
+                                          unsigned long long (*slots)[FPS_T / 64]) {
+    if constexpr (PPT == 1) {
+        if (n == T)
+            fps_pass<AR, 1, T, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+        else
+            fps_pass<AR, 1, T>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+    } else {
+        if (n == PPT * T)
+            fps_pass<AR, PPT, T, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+        else if (n <= PPT * T / 2)
+            fps_level<AR, T, PPT / 2>(n, m, sx, sy, sz, sel, slots);
+        else
+            fps_pass<AR, PPT, T>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+    }
+}
+
 // LDS (dynamic): coordinate planes A [3][n0] and B [3][m0] that the levels ping-pong between (every level is at most as large as
 // the one before, so level l+1 always fits the buffer level l-1 lived in) + the selected indices [m0]: 20.3 KB for 1024 -> 512 ->
 // 256 -> 128 - small enough to share a CU with a 135 KB score-network workgroup of another stream.
-template <int AR>
-__global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
+template <int AR, int T>
+__global__ __launch_bounds__(T) void fps_chain_kernel(FpsChainArgs a) {
     extern __shared__ float fps_lds[];
     __shared__ unsigned long long slots[2][FPS_T / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -283,7 +341,7 @@ __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
     float *plane[2] = {fps_lds, fps_lds + 3 * a.n0};
     int32_t *sel = reinterpret_cast<int32_t *>(fps_lds + 3 * a.n0 + 3 * a.m[0]);
     const float *xyz = a.xyz + (size_t)b * a.n0 * 3;
-    for (int i = tid; i < a.n0 * 3; i += FPS_T) {
+    for (int i = tid; i < a.n0 * 3; i += T) {
         int k = i / 3, c = i - k * 3;
         plane[0][c * cap[0] + k] = xyz[i];
     }
@@ -293,22 +351,11 @@ __global__ __launch_bounds__(FPS_T) void fps_chain_kernel(FpsChainArgs a) {
         const int m = a.m[l];
         float *sx = plane[buf], *sy = plane[buf] + cap[buf], *sz = plane[buf] + 2 * cap[buf];
         float *nx = plane[buf ^ 1], *ny = plane[buf ^ 1] + cap[buf ^ 1], *nz = plane[buf ^ 1] + 2 * cap[buf ^ 1];
-        if (n == 4 * FPS_T)
-            fps_pass<AR, 4, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
-        else if (n == 2 * FPS_T)
-            fps_pass<AR, 2, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
-        else if (n == FPS_T)
-            fps_pass<AR, 1, true>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
-        else if (n <= FPS_T)
-            fps_pass<AR, 1>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
-        else if (n <= 2 * FPS_T)
-            fps_pass<AR, 2>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
-        else
-            fps_pass<AR, 4>(n, m, as_lds(sx), as_lds(sy), as_lds(sz), nullptr, sel, slots);
+        fps_level<AR, T, 1024 / T>(n, m, sx, sy, sz, sel, slots);
         __syncthreads();
         int32_t *gi = a.idx[l] + (size_t)b * m;
         float *gx = a.new_xyz[l] + (size_t)b * m * 3;
-        for (int j = tid; j < m; j += FPS_T) {
+        for (int j = tid; j < m; j += T) {
             int s = sel[j];
             float x = sx[s], y = sy[s], z = sz[s];
             gi[j] = s;
@@ -553,16 +600,20 @@ int gp_furthest_point_sampling_arith(int arith, int b, int n, int m, const float
     hipStream_t st = (hipStream_t)s;
     const size_t lds = (size_t)n * 3 * sizeof(float);
     GP_ARITH_SWITCH(arith, {
-        if (n <= FPS_T)
-            hipLaunchKernelGGL((fps_kernel<AR, 1>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
-        else if (n <= 2 * FPS_T)
-            hipLaunchKernelGGL((fps_kernel<AR, 2>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
-        else if (n <= 4 * FPS_T)
-            hipLaunchKernelGGL((fps_kernel<AR, 4>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+        if (n <= FPS_W)
+            hipLaunchKernelGGL((fps_kernel<AR, 1, FPS_W>), dim3(b), dim3(FPS_W), lds, st, n, m, xyz, temp, idx);
+        else if (n <= 2 * FPS_W)
+            hipLaunchKernelGGL((fps_kernel<AR, 2, FPS_W>), dim3(b), dim3(FPS_W), lds, st, n, m, xyz, temp, idx);
+        else if (n <= 4 * FPS_W)
+            hipLaunchKernelGGL((fps_kernel<AR, 4, FPS_W>), dim3(b), dim3(FPS_W), lds, st, n, m, xyz, temp, idx);
+        else if (n <= 8 * FPS_W)
+            hipLaunchKernelGGL((fps_kernel<AR, 8, FPS_W>), dim3(b), dim3(FPS_W), lds, st, n, m, xyz, temp, idx);
+        else if (n <= 16 * FPS_W)
+            hipLaunchKernelGGL((fps_kernel<AR, 16, FPS_W>), dim3(b), dim3(FPS_W), lds, st, n, m, xyz, temp, idx);
         else if (n <= 8 * FPS_T)
-            hipLaunchKernelGGL((fps_kernel<AR, 8>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+            hipLaunchKernelGGL((fps_kernel<AR, 8, FPS_T>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
         else if (n <= FPS_MAXPPT * FPS_T)
-            hipLaunchKernelGGL((fps_kernel<AR, FPS_MAXPPT>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
+            hipLaunchKernelGGL((fps_kernel<AR, FPS_MAXPPT, FPS_T>), dim3(b), dim3(FPS_T), lds, st, n, m, xyz, temp, idx);
         else
             hipLaunchKernelGGL((fps_big_kernel<AR>), dim3(b), dim3(FPS_T), 0, st, n, m, xyz, temp, idx);
     })
@@ -593,7 +644,7 @@ int gp_fps_chain_arith(int arith, int b, int n0, int nlevels, const int *m, cons
         }
     }
     const size_t lds = ((size_t)3 * n0 + 4 * (size_t)a.m[0]) * sizeof(float);
-    GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((fps_chain_kernel<AR>), dim3(b), dim3(FPS_T), lds, (hipStream_t)s, a))
+    GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((fps_chain_kernel<AR, FPS_W>), dim3(b), dim3(FPS_W), lds, (hipStream_t)s, a))
     return gp_launch_status();
 }
 int gp_fps_chain(int b, int n0, int nlevels, const int *m, const float *xyz, int32_t *idx0, float *new_xyz0, int32_t *idx1,
