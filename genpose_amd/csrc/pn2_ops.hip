@@ -379,64 +379,83 @@ constexpr int BQ_T = 256;
 // many short waves' scalar chains, and more, shorter waves schedule best
 constexpr int BQ_CPW = 4;
 
+// LDS of a ball-query workgroup: the cloud as it lies in memory ([n][3]: lane k reads words 3k .. 3k+2 - stride 3 is coprime with the 64
+// banks) + per wave a staging row per scale of nsample slots and one dump slot
+__host__ __device__ constexpr size_t bq_lds_bytes(int n, int ns0, int ns1) {
+    return ((size_t)n * 3 + (size_t)(BQ_T / 64) * (size_t)(ns0 + 1 + (ns1 > 0 ? ns1 + 1 : 0))) * 4;
+}
+
 // One wave scans the cloud in index order, 64 candidates per step.  NS = number of scales (1 or 2).
-template <int AR, int NS, bool ZERO_FILL>
+// The kernel is bound by instruction issue (a REAL275-shaped level-0 centre finds 55 / 188 of 1024 candidates inside its two radii and scans
+// 8.9 of the 16 steps before both neighbourhoods are full), so a step is kept short: per scale one compare, v_mbcnt for the lane's slot, one
+// LDS write of the hits into the wave's staging row (slots past nsample fall into the dump slot: no second predicate, no per-lane 64-bit
+// global address, no scattered stores) and a scalar popcount; the row goes out with one coalesced store per centre, the first hit filling
+// the empty slots (ball_query_gpu.cu:35-39).  Round 4's form (hits stored straight to global memory, first hit tracked with s_ff1,
+// `if (mask)` / `if (count < nsample)` branches around each scale) took 85 instructions and 8 branches per step.
+template <int AR, int NS, bool ZERO_FILL, bool FULL>  // FULL: n % 64 == 0 (no bounds checks in the scan)
 __global__ __launch_bounds__(BQ_T) void ball_query_kernel(int n, int m, float r0, int ns0, float r1, int ns1,
                                                           const float *__restrict__ new_xyz, const float *__restrict__ xyz,
                                                           int32_t *__restrict__ idx0, int32_t *__restrict__ idx1) {
-    extern __shared__ float lds[];  // sx[n] sy[n] sz[n]
+    extern __shared__ float lds[];
     const int b = blockIdx.y;
     xyz += (size_t)b * n * 3;
-    float *sx = lds, *sy = lds + n, *sz = lds + 2 * n;
-    for (int i = threadIdx.x; i < n * 3; i += BQ_T) {
-        int k = i / 3, c = i - k * 3;
-        (c == 0 ? sx : c == 1 ? sy : sz)[k] = xyz[i];
+    if ((n & 3) == 0) {  // 12 n bytes per cloud: 16-byte aligned rows
+        const float4 *src = reinterpret_cast<const float4 *>(xyz);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < n * 3 / 4; i += BQ_T) dst[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < n * 3; i += BQ_T) lds[i] = xyz[i];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float rr0 = __fmul_rn(r0, r0), rr1 = __fmul_rn(r1, r1);  // ball_query_gpu.cu:23 (f32)
-    const unsigned long long below = (1ull << lane) - 1ull;
+    int32_t *st0 = reinterpret_cast<int32_t *>(lds + (size_t)n * 3) + wave * (ns0 + 1 + (NS > 1 ? ns1 + 1 : 0));
+    int32_t *st1 = st0 + ns0 + 1;
     for (int ci = 0; ci < BQ_CPW; ++ci) {
         const int p = (blockIdx.x * (BQ_T / 64) + wave) * BQ_CPW + ci;
         if (p >= m) break;
         const float *c = new_xyz + ((size_t)b * m + p) * 3;
         const float cx = c[0], cy = c[1], cz = c[2];
-        int32_t *o0 = idx0 + ((size_t)b * m + p) * ns0;
-        int32_t *o1 = NS > 1 ? idx1 + ((size_t)b * m + p) * ns1 : nullptr;
-        int cnt0 = 0, cnt1 = 0, first0 = 0, first1 = 0;
-        for (int base = 0; base < n; base += 64) {
+        int cnt0 = 0, cnt1 = 0;
+        const float *cand = lds + 3 * lane;
+        for (int base = 0; base < n; base += 64, cand += 3 * 64) {
             const int k = base + lane;
-            float d2 = 3.0e38f;
-            if (k < n) d2 = sqdist<AR>(cx, cy, cz, sx[k], sy[k], sz[k]);
-            if (cnt0 < ns0) {
-                unsigned long long mk = __ballot(k < n && d2 < rr0);
-                if (mk) {
-                    if (cnt0 == 0) first0 = base + __ffsll((long long)mk) - 1;
-                    int slot = cnt0 + __popcll(mk & below);
-                    if (((mk >> lane) & 1ull) && slot < ns0) o0[slot] = k;
-                    cnt0 += __popcll(mk);
-                }
+            const bool in = FULL || k < n;
+            const float *q = in ? cand : lds;
+            const float d2 = sqdist<AR>(cx, cy, cz, q[0], q[1], q[2]);
+            {
+                const bool hit = in && d2 < rr0;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(hit);
+                const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, (uint32_t)cnt0));
+                if (hit) st0[slot < ns0 ? slot : ns0] = k;
+                cnt0 += __popcll(mk);
             }
-            if (NS > 1 && cnt1 < ns1) {
-                unsigned long long mk = __ballot(k < n && d2 < rr1);
-                if (mk) {
-                    if (cnt1 == 0) first1 = base + __ffsll((long long)mk) - 1;
-                    int slot = cnt1 + __popcll(mk & below);
-                    if (((mk >> lane) & 1ull) && slot < ns1) o1[slot] = k;
-                    cnt1 += __popcll(mk);
-                }
+            if constexpr (NS > 1) {
+                const bool hit = in && d2 < rr1;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(hit);
+                const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, (uint32_t)cnt1));
+                if (hit) st1[slot < ns1 ? slot : ns1] = k;
+                cnt1 += __popcll(mk);
             }
             if (cnt0 >= ns0 && (NS == 1 || cnt1 >= ns1)) break;
         }
-        // first hit pre-fills every slot (ball_query_gpu.cu:35-39); no hit: untouched / zero
+        // a wave's LDS operations complete in order: the rows are read back by other lanes without a barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // hits in index order, then the first hit in every empty slot (ball_query_gpu.cu:35-39); no hit at all: untouched / zero
         if (cnt0 > 0 || ZERO_FILL) {
-            int v = cnt0 > 0 ? first0 : 0;
-            for (int sl = (cnt0 < ns0 ? cnt0 : ns0) + lane; sl < ns0; sl += 64) o0[sl] = v;
+            int32_t *o0 = idx0 + ((size_t)b * m + p) * ns0;
+            const int first = cnt0 > 0 ? st0[0] : 0;
+            for (int sl = lane; sl < ns0; sl += 64) o0[sl] = sl < cnt0 ? st0[sl] : first;
         }
         if (NS > 1 && (cnt1 > 0 || ZERO_FILL)) {
-            int v = cnt1 > 0 ? first1 : 0;
-            for (int sl = (cnt1 < ns1 ? cnt1 : ns1) + lane; sl < ns1; sl += 64) o1[sl] = v;
+            int32_t *o1 = idx1 + ((size_t)b * m + p) * ns1;
+            const int first = cnt1 > 0 ? st1[0] : 0;
+            for (int sl = lane; sl < ns1; sl += 64) o1[sl] = sl < cnt1 ? st1[sl] : first;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -657,10 +676,16 @@ int gp_ball_query_arith(int arith, int b, int n, int m, float radius, int nsampl
     if (!arith_ok(arith) || b < 0 || n <= 0 || m < 0 || nsample <= 0 || !new_xyz || !xyz || !idx) return GP_EINVAL;
     if (b == 0 || m == 0) return GP_OK;
     hipStream_t st = (hipStream_t)s;
-    if ((size_t)n * 12 <= 60 * 1024) {
+    if (bq_lds_bytes(n, nsample, 0) <= 60 * 1024) {
         dim3 grid((m + (BQ_T / 64) * BQ_CPW - 1) / ((BQ_T / 64) * BQ_CPW), b);
-        GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((ball_query_kernel<AR, 1, false>), grid, dim3(BQ_T), (size_t)n * 12, st, n, m, radius, nsample,
-                                                  0.f, 0, new_xyz, xyz, idx, (int32_t *)nullptr))
+        GP_ARITH_SWITCH(arith, {
+            if (n % 64 == 0)
+                hipLaunchKernelGGL((ball_query_kernel<AR, 1, false, true>), grid, dim3(BQ_T), bq_lds_bytes(n, nsample, 0), st, n, m, radius, nsample, 0.f, 0,
+                                   new_xyz, xyz, idx, (int32_t *)nullptr);
+            else
+                hipLaunchKernelGGL((ball_query_kernel<AR, 1, false, false>), grid, dim3(BQ_T), bq_lds_bytes(n, nsample, 0), st, n, m, radius, nsample, 0.f, 0,
+                                   new_xyz, xyz, idx, (int32_t *)nullptr);
+        })
     } else {
         dim3 grid((m + BQ_T / 64 - 1) / (BQ_T / 64), b);
         GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((ball_query_big_kernel<AR>), grid, dim3(BQ_T), 0, st, n, m, radius, nsample, new_xyz, xyz, idx))
@@ -674,11 +699,17 @@ int gp_ball_query(int b, int n, int m, float radius, int nsample, const float *n
 int gp_ball_query_msg_arith(int arith, int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
                             const float *xyz, int32_t *idx0, int32_t *idx1, gp_stream_t s) {
     if (!arith_ok(arith) || b < 0 || n <= 0 || m < 0 || nsample0 <= 0 || nsample1 <= 0 || !new_xyz || !xyz || !idx0 || !idx1) return GP_EINVAL;
-    if ((size_t)n * 12 > 60 * 1024) return GP_EINVAL;
+    if (bq_lds_bytes(n, nsample0, nsample1) > 60 * 1024) return GP_EINVAL;
     if (b == 0 || m == 0) return GP_OK;
     dim3 grid((m + (BQ_T / 64) * BQ_CPW - 1) / ((BQ_T / 64) * BQ_CPW), b);
-    GP_ARITH_SWITCH(arith, hipLaunchKernelGGL((ball_query_kernel<AR, 2, true>), grid, dim3(BQ_T), (size_t)n * 12, (hipStream_t)s, n, m, radius0,
-                                              nsample0, radius1, nsample1, new_xyz, xyz, idx0, idx1))
+    GP_ARITH_SWITCH(arith, {
+        if (n % 64 == 0)
+            hipLaunchKernelGGL((ball_query_kernel<AR, 2, true, true>), grid, dim3(BQ_T), bq_lds_bytes(n, nsample0, nsample1), (hipStream_t)s, n, m, radius0,
+                               nsample0, radius1, nsample1, new_xyz, xyz, idx0, idx1);
+        else
+            hipLaunchKernelGGL((ball_query_kernel<AR, 2, true, false>), grid, dim3(BQ_T), bq_lds_bytes(n, nsample0, nsample1), (hipStream_t)s, n, m, radius0,
+                               nsample0, radius1, nsample1, new_xyz, xyz, idx0, idx1);
+    })
     return gp_launch_status();
 }
 int gp_ball_query_msg(int b, int n, int m, float radius0, int nsample0, float radius1, int nsample1, const float *new_xyz,
