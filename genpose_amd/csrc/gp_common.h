@@ -290,14 +290,27 @@ __device__ __forceinline__ float row8_max(float v) {
 // weights as B (the per-lane fragments are the same registers either way) - gives D^T: lane = channel 16 n + (lane & 15), the four
 // registers x four lane groups = the 16 points.  The max over the points is then 3 in-lane max + two permlane swaps (7 instructions
 // per 16 channels) instead of 4 DPP steps for each of the 4 registers (32); every lane ends up with the maximum.
+//
+// On this part an fp32 MFMA executes on the SIMD's FMA lanes - every other VALU instruction a wave issues takes four cycles away from the
+// matrix work (measured over all kernels of the encoder: time per MFMA = 32 cycles + 4 x the VALU instructions per MFMA), so the
+// instruction count of an epilogue IS its cost.  As fmaxf() the compiler must first quiet possible signalling NaNs of every input that is
+// not the result of an arithmetic instruction (MFMA results, permlane results: IEEE mode) - `v_max_f32 x, x, x`, 8 of the 15 VALU
+// instructions this function used to be.  v_med3_f32(a, b, +inf) is max(a, b) for non-NaN inputs and is selected as written.
+// (NOT inline asm: the hazard recogniser does not look into it, and an MFMA result needs up to 11 wait states before a VALU read.)
+// (the +inf goes through an empty asm: the optimiser folds fmed3(a, b, +inf) back into maxnum - and its canonicalisation - otherwise)
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float inf = __builtin_inff();
+    asm("" : "+s"(inf));
+    return __builtin_amdgcn_fmed3f(a, b, inf);
+}
 __device__ __forceinline__ float points16_max_t(const f32x4 &v) {
-    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    float m = max_raw(max_raw(v.x, v.y), max_raw(v.z, v.w));
     const int a = __float_as_int(m);
     const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);  // {g0,g0,g2,g2} , {g1,g1,g3,g3}
-    m = fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
+    m = max_raw(__int_as_float(r[0]), __int_as_float(r[1]));
     const int b = __float_as_int(m);
     const auto q = __builtin_amdgcn_permlane32_swap(b, b, false, false);  // {lo,lo} , {hi,hi}
-    return fmaxf(__int_as_float(q[0]), __int_as_float(q[1]));
+    return max_raw(__int_as_float(q[0]), __int_as_float(q[1]));
 }
 __device__ __forceinline__ float row16_sum(float v) {
     v += __shfl_xor(v, 1, 64);

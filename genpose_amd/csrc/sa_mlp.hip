@@ -421,7 +421,7 @@ int launch_pre(const SAPreArgs &a, int b, hipStream_t st) {
 // The tile-based kernel above spends its time on barriers and dependent global round trips here (measured 111 + 306 us
 // for the two scales at B = 64 against ~10 + 45 us of MFMA work).
 template <int C1, int C2, int C3, int NS>
-__global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentres_total) {
+__global__ __launch_bounds__(256, 3) void sa0_chain_kernel(SAPreArgs a, int ncentres_total) {
     constexpr int PT = NS / 16, Q1 = C1 / 16, Q2 = C2 / 16, Q3 = C3 / 16;
     const int lane = threadIdx.x & 63, pt = lane & 15, g = lane >> 4;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void sa0_chain_kernel(SAPreArgs a, int ncentre
 // (ds_read_b128, 1 KB per wave-instruction, lane-linear = conflict free) while it walks its own neighbourhoods:
 // no L2 weight traffic after the prologue, no LDS activation traffic, no barriers in the loop.
 template <int C1, int C2, int C3, int NS>
-__global__ __launch_bounds__(256) void sa_chain_lds_kernel(SAPreArgs a, int ncentres_total) {
+__global__ __launch_bounds__(256, 3) void sa_chain_lds_kernel(SAPreArgs a, int ncentres_total) {
     constexpr int PT = NS / 16, Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f32x4 *w2l = reinterpret_cast<f32x4 *>(lds);           // [Q1][Q2][64]
