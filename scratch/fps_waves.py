@@ -1,8 +1,6 @@
-"""Furthest point sampling: waves per cloud (GP_FPS_WAVES = 1 / 2 / 4, read once by the library - TUNING ONLY).
+"""Furthest point sampling (one wave per cloud for n <= 1024): python scratch/fps_waves.py
 
-    for w in 1 2 4; do GP_FPS_WAVES=$w python scratch/fps_waves.py; done
-
-Every form is first held to the oracle (indices of every level, bit for bit, all three distance conventions), then timed with HIP events:
+(Round 5 compared one / two / four waves per cloud through a tuning-only switch: profiles/r5_fps_one_wave.txt.)  The kernel is first held to the oracle (indices of every level, bit for bit, all three distance conventions), then timed with HIP events:
 the encoder's chain (1024 -> 512 -> 128), level 0 alone, and the stand-alone operator at a few (n, m).
 """
 import os
@@ -49,7 +47,6 @@ def timed(fn, reps=20):
 
 
 def main():
-    waves = os.environ.get("GP_FPS_WAVES", "1")
     dev = torch.device("cuda:0")
     pts = torch.from_numpy(synth.make_batch(64, start=5)).to(dev).contiguous()
     # parity first
@@ -73,12 +70,12 @@ def main():
         ref, rtemp = pn2_oracle.furthest_point_sampling(x.cpu().numpy(), m)
         assert np.array_equal(ref, idx.cpu().numpy()), (n, m)
         assert np.array_equal(rtemp, temp.cpu().numpy()), (n, m)
-    print(f"[waves {waves}] parity with the oracle: chain (3 conventions, 3 level sets), operator at 6 shapes incl. ties - OK")
+    print(f"parity with the oracle: chain (3 conventions, 3 level sets), operator at 6 shapes incl. ties - OK")
     for B in (5, 64, 320, 640):
         x = torch.from_numpy(synth.make_batch(B)).to(dev).contiguous()
-        t_chain = timed(lambda: chain(x, (512, 128), "B"))
+        t_chain = timed(lambda: chain(x, (512, 256, 128), "B"))
         t_l0 = timed(lambda: chain(x, (512,), "B"))
-        print(f"[waves {waves}] {B:4d} clouds: chain 1024->512->128 {t_chain:7.1f} us   level 0 alone {t_l0:7.1f} us")
+        print(f"{B:4d} clouds: chain 1024->512->256->128 {t_chain:7.1f} us   level 0 alone {t_l0:7.1f} us")
 
 
 if __name__ == "__main__":

@@ -25,6 +25,9 @@ timeout 200 python scratch/pc_bf16x3_time.py > $O/pc_bf16x3_plans.txt 2>&1
 for mode in forward graph; do for B in 5 64 320 640; do timeout 100 python scratch/enc_profile.py $B 30 $mode 2>/dev/null | tail -1; done; done > $O/encoder_wall.txt
 for B in 320 640; do timeout 100 python scratch/enc_profile.py $B 30 graph bf16x3 2>/dev/null | tail -1; done >> $O/encoder_wall.txt
 bash scratch/enc_kernel_stats.sh 320 $O/encoder320_kernel_stats.txt > /dev/null 2>&1
+bash scratch/enc_timeline.sh 320 graph $O/encoder320_timeline.txt > /dev/null 2>&1
+timeout 120 python scratch/fps_waves.py > $O/fps_one_wave.txt 2>&1
+timeout 120 python scratch/ubench/run.py > $O/ubench_valu_beside_mfma.txt 2>&1
 GP_ENC_PRECISION=bf16x3 bash scratch/enc_kernel_stats.sh 320 $O/encoder320_bf16x3_kernel_stats.txt > /dev/null 2>&1
 rm -rf /tmp/prof_trk; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trk -o trk -- python scratch/track_one.py > $O/track_one.log 2>&1
 python - "$(find /tmp/prof_trk -name '*kernel_stats.csv' | head -1)" > $O/tracking_kernels.txt <<'PY'
