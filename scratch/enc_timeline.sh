@@ -10,7 +10,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows = [r for r in rows if "at::native" not in r["Kernel_Name"] and "rocclr" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last pass starts at the last fps_chain launch that samples level 0 (first fps kernel of a pass)
-starts = [i for i, r in enumerate(rows) if "fps_chain" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "fps_" in r["Kernel_Name"]]
 # passes launch one or two fps chains; take the last chain whose predecessor is not an fps chain within 50 us
 first = starts[-1]
 for i in reversed(starts):
