@@ -3,12 +3,13 @@
 // (networks/pts_encoder/pointnet2_utils/pointnet2/src/*.cu) behind the C ABI of include/genpose_hip.h.
 //
 // Design (wave64, LDS-staged):
-//  * FPS: one 256-thread workgroup per cloud, coordinates and running min-distances live in registers,
-//    the cloud is mirrored in LDS only for the broadcast read of the last selected point; argmax is a
-//    packed-key max (distance bits | tie rank) -> 6 DPP/shuffle steps per wave + one LDS exchange and
-//    ONE barrier per selected point.  The tie rank reproduces the reference's shared-memory tree
-//    (sampling_gpu.cu:86-91,143-203): smallest bit-reversed slot wins.
-//  * ball query: one wave per centre, 64 candidates per step, ballot + prefix popcount keeps index order.
+//  * FPS: ONE WAVE per cloud for n <= 1024 (four waves up to 4096 points), coordinates and running min-distances live in registers,
+//    the cloud is mirrored in LDS only for the broadcast read of the last selected point; a point's (tie rank, distance bits) is one
+//    64-bit register pair, the lane's best pair a tree of v_max_f64, the wave's two six-step v_max_u32_dpp reductions - no LDS
+//    exchange and no barrier in the pick loop of the one-wave form (fps_pass).  The tie rank reproduces the reference's
+//    shared-memory tree (sampling_gpu.cu:86-91,143-203): smallest bit-reversed slot wins.
+//  * ball query: one wave per centre, 64 candidates per step; compare -> v_mbcnt slot -> LDS staging row keeps index order, one
+//    coalesced store per centre (ball_query_kernel).
 //  * distances: `dx*dx + dy*dy + dz*dz` (sampling_gpu.cu:133, ball_query_gpu.cu:33, interpolate_gpu.cu:36) under one of three
 //    contraction conventions (GP_ARITH_A / _B / _C, include/genpose_hip.h) - a TEMPLATE parameter of every kernel that
 //    evaluates it (no run-time cost), spelled with __fmaf_rn/__fmul_rn/__fadd_rn so hipcc cannot re-associate or re-contract it.
