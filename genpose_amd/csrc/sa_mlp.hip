@@ -21,21 +21,23 @@ struct SAArgs {
 };
 
 // layer 3 + max over the neighbourhood, straight from the accumulators (WN waves along channels, PT p-chunks per wave)
+// [nc_lo, nc_hi): the 16-channel output chunks this workgroup computes (all of them unless the launch splits the channels, launch_pre)
 template <int PT, int WN>
-__device__ __forceinline__ void layer3_max(const SAArgs &a, const float *A, int lda, int c2p, int row0, int b) {
+__device__ __forceinline__ void layer3_max(const SAArgs &a, const float *A, int lda, int c2p, int row0, int b, int nc_lo = 0, int nc_hi = 1 << 30) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wn = wave % WN, wp = wave / WN;
     const int KG = c2p / 16, NC = gp_round16(a.c3) / 16;
+    if (nc_hi > NC) nc_hi = NC;
     const int pc0 = wp * PT;
     const int G = a.groupall ? PT : (a.ns >= 16 ? a.ns / 16 : 1);  // p-chunks per centre (nsample = 8: two centres per p-chunk)
     const bool half = !a.groupall && a.ns == 8;
     float *outb = a.out + (size_t)b * a.np * a.cout_total + a.cout_off;
-    for (int ncb = wn; ncb < NC; ncb += WN * 4) {
+    for (int ncb = nc_lo + wn; ncb < nc_hi; ncb += WN * 4) {
         int nc[4], nv = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             nc[i] = ncb + i * WN;
-            nv += nc[i] < NC;
+            nv += nc[i] < nc_hi;
         }
         f32x4 acc[4][PT];
         mfma_tile_n<PT>(nv, A, lda, pc0, a.w3, KG, NC, nc, acc);
@@ -386,14 +388,19 @@ __global__ __launch_bounds__(256) void sa_pre_mlp_kernel(SAPreArgs a) {
     l3.xyz = nullptr, l3.feats_in = nullptr, l3.new_xyz = nullptr, l3.idx = nullptr;
     l3.w1 = l3.b1 = l3.w2 = l3.b2 = nullptr, l3.w3 = a.w3, l3.b3 = a.b3;
     l3.out = a.out, l3.cout_total = a.cout_total, l3.cout_off = a.cout_off, l3.groupall = a.groupall;
-    const int wn = pick_wn(gp_round16(a.c3) / 16, P, a.groupall ? 16 : a.ns);
+    // channel split (gridDim.z workgroups per row tile, launch_pre): every workgroup has computed layers 1-2 for its rows and takes its
+    // share of the last layer's output chunks - same MFMA order per output, so the results are those of the unsplit launch, bit for bit
+    const int NC3 = gp_round16(a.c3) / 16, per = (NC3 + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int nc_lo = (int)blockIdx.z * per, nc_hi = nc_lo + per < NC3 ? nc_lo + per : NC3;
+    if (nc_lo >= nc_hi) return;
+    const int wn = pick_wn(nc_hi - nc_lo, P, a.groupall ? 16 : a.ns);
     if constexpr (P >= 64) {
-        if (wn == 1) return layer3_max<P / 64, 1>(l3, A, lda, c2p, row0, b);
+        if (wn == 1) return layer3_max<P / 64, 1>(l3, A, lda, c2p, row0, b, nc_lo, nc_hi);
     }
     if constexpr (P >= 32) {
-        if (wn == 2) return layer3_max<P / 32, 2>(l3, A, lda, c2p, row0, b);
+        if (wn == 2) return layer3_max<P / 32, 2>(l3, A, lda, c2p, row0, b, nc_lo, nc_hi);
     }
-    layer3_max<P / 16, 4>(l3, A, lda, c2p, row0, b);
+    layer3_max<P / 16, 4>(l3, A, lda, c2p, row0, b, nc_lo, nc_hi);
 }
 
 template <int P>
@@ -407,7 +414,16 @@ int launch_pre(const SAPreArgs &a, int b, hipStream_t st) {
             return GP_ELAUNCH;
     }
     const int nrows = a.groupall ? a.n : a.np * a.ns;
-    hipLaunchKernelGGL(kern, dim3((nrows + P - 1) / P, b), dim3(256), lds, st, a);
+    const int tiles = (nrows + P - 1) / P;
+    // The GroupAll level of a SMALL batch (a tracking frame: 5 clouds = 20 tiles; one cloud: 4): every tile streams all of both weight
+    // matrices (0.77 / 1.15 MB) through one CU while the others idle - 48 us per launch whatever the batch.  While the chip has CUs to spare,
+    // 2 or 4 workgroups share a row tile: each recomputes layers 1-2 (a third of the work) and takes a half / quarter of layer 3's channels.
+    int split = 1;
+    if (a.groupall) {
+        const int ncu = gp_num_cus();
+        split = tiles * b * 4 <= ncu ? 4 : (tiles * b * 2 <= ncu ? 2 : 1);
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, b, split), dim3(256), lds, st, a);
     return gp_launch_status();
 }
 
@@ -1153,7 +1169,16 @@ int launch(const SAArgs &a, int b, hipStream_t st) {
             return GP_ELAUNCH;
     }
     const int nrows = a.groupall ? a.n : a.np * a.ns;
-    hipLaunchKernelGGL(kern, dim3((nrows + P - 1) / P, b), dim3(256), lds, st, a);
+    const int tiles = (nrows + P - 1) / P;
+    // The GroupAll level of a SMALL batch (a tracking frame: 5 clouds = 20 tiles; one cloud: 4): every tile streams all of both weight
+    // matrices (0.77 / 1.15 MB) through one CU while the others idle - 48 us per launch whatever the batch.  While the chip has CUs to spare,
+    // 2 or 4 workgroups share a row tile: each recomputes layers 1-2 (a third of the work) and takes a half / quarter of layer 3's channels.
+    int split = 1;
+    if (a.groupall) {
+        const int ncu = gp_num_cus();
+        split = tiles * b * 4 <= ncu ? 4 : (tiles * b * 2 <= ncu ? 2 : 1);
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, b, split), dim3(256), lds, st, a);
     return gp_launch_status();
 }
 
