@@ -440,7 +440,7 @@ template <int C1, int C2, int C3, int NS>
 __global__ __launch_bounds__(256, 3) void sa0_chain_kernel(SAPreArgs a, int ncentres_total) {
     constexpr int PT = NS / 16, Q1 = C1 / 16, Q2 = C2 / 16, Q3 = C3 / 16;
     const int lane = threadIdx.x & 63, pt = lane & 15, g = lane >> 4;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int wave_global = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4;  // (scalar: the centre index and everything addressed through it stay on the scalar unit)
     // ---- per-lane constants: layer-1 rows for channels 16q + 4g + {0..3}; A fragments of layers 2 and 3; biases
     f32x4 w1[Q1][4], bb1[Q1];
 #pragma unroll
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 3) void sa_chain_lds_kernel(SAPreArgs a, int n
 #pragma unroll
     for (int n = 0; n < Q3; ++n) bb3[n] = a.b3[16 * n + pt];
     __syncthreads();
-    const int wave_global = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
+    const int wave_global = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = gridDim.x * 4;  // (scalar, as in sa0_chain_kernel)
     // The wave walks 16-row chunks: iteration `it` is chunk p = it % PT of the wave's (it / PT)-th neighbourhood, so the
     // per-iteration register footprint is one chunk whatever the neighbourhood size (the running max lives in `res`).
     const int my_centres = wave_global < ncentres_total ? (ncentres_total - wave_global + nwaves - 1) / nwaves : 0;
@@ -788,7 +788,10 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
         hold[u] = w3g[(2 % Q2) * SLICE + tid + u * NTH];
     }
     __syncthreads();
-    const int wave_global = blockIdx.x * NWV + (tid >> 6), nwaves = gridDim.x * NWV;
+    // the wave's index as a SCALAR (the centre index and everything addressed through it stay on the scalar unit: -7 % VALU instructions,
+    // -2.8 % time at NS = 32); at NS = 16 the same change measured +1.3 % (another schedule of the same loop), so that form keeps the vector index
+    const int wave_in_wg = NS == 16 ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_global = blockIdx.x * NWV + wave_in_wg, nwaves = gridDim.x * NWV;
     const int my_centres = wave_global < ncentres_total ? (ncentres_total - wave_global + nwaves - 1) / nwaves : 0;
     const int nits = my_centres * PT;
     const int nits_wg = ((ncentres_total + nwaves - 1) / nwaves) * PT;  // uniform over the grid: barrier counts match
