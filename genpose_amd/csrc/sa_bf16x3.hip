@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512) void sa_chain_bf16x3_kernel(SABfArgs a, int nu
         for (int e = tid; e < NSL * SLICE; e += NTH) ring[e] = a.w3[e];
     }
     __syncthreads();
-    const int wave_global = blockIdx.x * NWV + (tid >> 6), nwaves = gridDim.x * NWV;
+    const int wave_global = blockIdx.x * NWV + __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = gridDim.x * NWV;  // (scalar, as in the fp32 chain kernels)
     const int my_units = wave_global < nunits_total ? (nunits_total - wave_global + nwaves - 1) / nwaves : 0;
     // RING: every wave runs the same number of iterations (idle ones compute on clamped rows and store nothing): barrier counts match
     const int nits_wg = RING ? (nunits_total + nwaves - 1) / nwaves : my_units;

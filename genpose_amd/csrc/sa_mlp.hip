@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void point_linear_kernel(int M, int K, int N, 
                                                            float *__restrict__ Z) {
     constexpr int P = 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * P, Kp = gp_round16(K), ld = Kp + GP_LD_PAD;
     const int q4 = K >> 2;
     for (int e = tid; e < P * q4; e += 256) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, WGS) void point_linear_ws_kernel(int M, int N,
     constexpr int PRE = R * (K / 4) / 256;  // f32x4 per thread and tile
     static_assert(R * (K / 4) % 256 == 0, "tile size");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NC = N / 16, c0 = (blockIdx.y * 4 + wave) * NCW;
     f32x4 wr[NCW][KB];
 #pragma unroll
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(512) void sa_groupall_ring_kernel(SAPreArgs a, int 
     f32x4 *w1l = ring + NRS * SLOT;                        // [C1] rows (wx, wy, wz, b1)
     float *pool = reinterpret_cast<float *>(w1l + C1);     // [NWV][C3] per-wave maxima of the pre-bias layer-3 output
     float *b2l = pool + NWV * C3;                          // [C2]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pt = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), pt = lane & 15;
     const f32x4 *w2g = reinterpret_cast<const f32x4 *>(a.w2), *w3g = reinterpret_cast<const f32x4 *>(a.w3);
     // slice si of the per-cloud stream: base pointer and fragment count
     auto slice = [&](int si, int &nfrag) -> const f32x4 * {

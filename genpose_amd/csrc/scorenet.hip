@@ -350,7 +350,7 @@ template <int PT, int MODEL>
 __global__ __launch_bounds__(gp_chain::NT, 1) void pc_step_chain_kernel(PcArgs a, gp_scorenet net) {
     using C = gp_chain::Cfg<PT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pt = lane & 15, g = lane >> 4, i = a.step;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), pt = lane & 15, g = lane >> 4, i = a.step;
     const int wg_row0 = blockIdx.x * C::ROWS;
     gp_chain::State<PT> st;
     const float *tvec = a.tvec_all + (size_t)(i < a.nsteps ? i : 0) * HEADS;

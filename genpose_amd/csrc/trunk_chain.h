@@ -116,7 +116,7 @@ template <int PT>
 __device__ __forceinline__ void begin_request(State<PT> &st, Staged<PT> &sg, const gp_scorenet &net, const float *__restrict__ cvec,
                                               const float *__restrict__ tvec, int wg_row0, int row_end, int kcand) {
     using C = Cfg<PT>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
     for (int t = 0; t < C::W; ++t) {
         const SliceSrc src = slice_src(net, t);
