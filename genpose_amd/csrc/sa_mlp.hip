@@ -756,7 +756,10 @@ int launch_chain_lds(const SAPreArgs &a, int b, hipStream_t st) {
 // SPREAD (hidden-layer layout GP_SA_TAIL_SPREAD, genpose_hip.h): the r = C2 % 16 channels of the last, partly filled 16-channel block
 // sit at positions 4 (c % 4) + c / 4, i.e. in k-steps jj < ceil(r / 4) of all four lane groups, so layer 3 skips the k-steps of
 // that block that only multiply padding (196 channels: one MFMA instead of four, -5.8 % of layer 3).
-template <int C1, int C2, int C3, int NS, bool SPREAD>
+// SPLITP (small batches: fewer neighbourhoods than the chip has wave slots for): the unit of work is one 16-row CHUNK of a neighbourhood
+// instead of the neighbourhood - twice the waves, half the iterations; a unit applies bias and ReLU to its own maximum and combines with
+// the neighbourhood's other chunk through an integer atomic max (values >= 0: the order of the bit patterns) into the ZEROED output.
+template <int C1, int C2, int C3, int NS, bool SPREAD, bool SPLITP = false>
 __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int ncentres_total) {
     constexpr int PT = NS / 16, Q1 = C1 / 16, Q2 = (C2 + 15) / 16, Q3 = C3 / 16, NWV = 8, NTH = 512;
     constexpr int TAIL_JJ = (SPREAD && C2 % 16) ? (C2 % 16 + 3) / 4 : 4;  // k-steps of the last k-block that carry channels
@@ -792,10 +795,16 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
     // -2.8 % time at NS = 32); at NS = 16 the same change measured +1.3 % (another schedule of the same loop), so that form keeps the vector index
     const int wave_in_wg = NS == 16 ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_global = blockIdx.x * NWV + wave_in_wg, nwaves = gridDim.x * NWV;
-    const int my_centres = wave_global < ncentres_total ? (ncentres_total - wave_global + nwaves - 1) / nwaves : 0;
-    const int nits = my_centres * PT;
-    const int nits_wg = ((ncentres_total + nwaves - 1) / nwaves) * PT;  // uniform over the grid: barrier counts match
+    const int nunits = SPLITP ? ncentres_total * PT : ncentres_total;   // what the waves share out: chunks or whole neighbourhoods
+    const int my_units = wave_global < nunits ? (nunits - wave_global + nwaves - 1) / nwaves : 0;
+    const int nits = SPLITP ? my_units : my_units * PT;
+    const int nits_wg = ((nunits + nwaves - 1) / nwaves) * (SPLITP ? 1 : PT);  // uniform over the grid: barrier counts match
     auto chunk_row0 = [&](int it, int &c) {
+        if constexpr (SPLITP) {
+            const int u = wave_global + it * nwaves;
+            c = u / PT;
+            return (size_t)c * NS + (size_t)(u % PT) * 16;
+        }
         c = wave_global + (it / PT) * nwaves;
         return (size_t)c * NS + (size_t)(it % PT) * 16;
     };
@@ -912,15 +921,23 @@ __global__ __launch_bounds__(512) void sa_chain_ring_kernel(SAPreArgs a, int nce
             __syncthreads();
         }
         {
-            const int c = wave_global + (it / PT) * nwaves;
+            int c;
+            chunk_row0(it, c);
             float *o = a.out + (size_t)(it < nits ? c : 0) * a.cout_total + a.cout_off;
             // layer 3 ran transposed: lane = channel 16 n + pt, the 16 rows are the registers x lane groups (points16_max_t);
             // max_i relu(x_i + b) = relu(max_i x_i + b), so bias and ReLU come once per channel after the pooling
 #pragma unroll
             for (int n = 0; n < Q3; ++n) {
                 const float m = points16_max_t(acc3[n]);
-                res[n] = p == 0 ? m : fmaxf(res[n], m);  // running max over the neighbourhood's chunks: one register per chunk
-                if (p == PT - 1 && g == 0 && it < nits) o[16 * n + pt] = fmaxf(res[n] + b3l[16 * n + (lo & 15)], 0.f);
+                if constexpr (SPLITP) {
+                    // the chunk's own relu(max + b) (>= 0: its bit pattern orders like a signed integer), combined with the neighbourhood's
+                    // other chunk in the zeroed output: max_chunks relu(max_chunk + b) = relu(max_all + b)
+                    const float v = fmaxf(m + b3l[16 * n + (lo & 15)], 0.f);
+                    if (g == 0 && it < nits) atomicMax(reinterpret_cast<int *>(o + 16 * n + pt), __float_as_int(v));
+                } else {
+                    res[n] = p == 0 ? m : fmaxf(res[n], m);  // running max over the neighbourhood's chunks: one register per chunk
+                    if (p == PT - 1 && g == 0 && it < nits) o[16 * n + pt] = fmaxf(res[n] + b3l[16 * n + (lo & 15)], 0.f);
+                }
             }
         }
     }
@@ -1145,6 +1162,24 @@ int launch_chain_ring(const SAPreArgs &a, int b, hipStream_t st) {
         done = true;
     }
     const int ncentres = b * a.np;
+    if constexpr (NS > 16) {
+        // a small batch (a tracking frame: 5 clouds = 640 neighbourhoods = 80 workgroups): the chunks of a neighbourhood go to different
+        // waves while that still fits one workgroup per CU - half the iterations (89 -> ~50 us at 5 clouds)
+        constexpr int PT = NS / 16;
+        if (ncentres * PT <= 8 * gp_num_cus()) {
+            auto kern_s = sa_chain_ring_kernel<C1, C2, C3, NS, SPREAD, true>;
+            static bool done_s = false;
+            if (!done_s) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return GP_ELAUNCH;
+                done_s = true;
+            }
+            if (hipMemset2DAsync(a.out + a.cout_off, (size_t)a.cout_total * sizeof(float), 0, (size_t)C3 * sizeof(float), (size_t)ncentres, st) != hipSuccess)
+                return GP_ELAUNCH;
+            hipLaunchKernelGGL(kern_s, dim3((ncentres * PT + 7) / 8), dim3(512), lds, st, a, ncentres);
+            return gp_launch_status();
+        }
+    }
     int blocks = (ncentres + 7) / 8;
     if (blocks > gp_num_cus()) blocks = gp_num_cus();  // persistent, one 8-wave workgroup per CU (154 KB LDS)
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, a, ncentres);
