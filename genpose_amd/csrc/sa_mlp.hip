@@ -756,6 +756,12 @@ int launch_chain_lds(const SAPreArgs &a, int b, hipStream_t st) {
 // SPREAD (hidden-layer layout GP_SA_TAIL_SPREAD, genpose_hip.h): the r = C2 % 16 channels of the last, partly filled 16-channel block
 // sit at positions 4 (c % 4) + c / 4, i.e. in k-steps jj < ceil(r / 4) of all four lane groups, so layer 3 skips the k-steps of
 // that block that only multiply padding (196 channels: one MFMA instead of four, -5.8 % of layer 3).
+// out[r][0 .. 4 w4) = 0 for the rows of a [rows][ld] tensor: the zeroed output the SPLITP form below combines into
+__global__ __launch_bounds__(256) void zero_columns_kernel(float *out, int ld, int w4, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < total) *reinterpret_cast<f32x4 *>(out + (size_t)(e / w4) * ld + 4 * (e % w4)) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // SPLITP (small batches: fewer neighbourhoods than the chip has wave slots for): the unit of work is one 16-row CHUNK of a neighbourhood
 // instead of the neighbourhood - twice the waves, half the iterations; a unit applies bias and ReLU to its own maximum and combines with
 // the neighbourhood's other chunk through an integer atomic max (values >= 0: the order of the bit patterns) into the ZEROED output.
@@ -1174,8 +1180,10 @@ int launch_chain_ring(const SAPreArgs &a, int b, hipStream_t st) {
                     return GP_ELAUNCH;
                 done_s = true;
             }
-            if (hipMemset2DAsync(a.out + a.cout_off, (size_t)a.cout_total * sizeof(float), 0, (size_t)C3 * sizeof(float), (size_t)ncentres, st) != hipSuccess)
-                return GP_ELAUNCH;
+            // (a KERNEL, not hipMemset2DAsync: as a memset node of a graph captured on a side stream - the tracking runner's energy-model
+            // graph - the zeroing was not ordered before the kernel on replay, and the atomic max then kept stale values)
+            hipLaunchKernelGGL(zero_columns_kernel, dim3((ncentres * (C3 / 4) + 255) / 256), dim3(256), 0, st, a.out + a.cout_off, a.cout_total, C3 / 4,
+                               ncentres * (C3 / 4));
             hipLaunchKernelGGL(kern_s, dim3((ncentres * PT + 7) / 8), dim3(512), lds, st, a, ncentres);
             return gp_launch_status();
         }

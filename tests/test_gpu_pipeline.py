@@ -271,11 +271,27 @@ def test_tracking_frame_graphs_equal_the_agent_calls():
     for graphs in (True, False):
         tr = TrackingRunner(sa, ea, repeat_num=K, T0=0.15, use_graphs=graphs)
         res = []
+        snaps = []
         for pts, names, gt, draws, prior in frames:
             sa.net.prior_fn = lambda shape, T=1.0, p=prior: p.clone()
             res.append({k: v.clone() for k, v in tr.step(pts, names, gt, noise_draws=draws).items()})
+            if graphs:  # what the replayed graphs left in both encoders' workspaces and in their static outputs (snapshots on the calling
+                #         stream, which rank() has already ordered after the side stream: no host synchronisation between frames)
+                key = (tuple(pts.shape), pts.dtype)
+                levels = [[f.clone() for f in a.net.pts_encoder._workspace(pts.shape[0], pts.shape[1], tr._graphs.SLOT)["feat"]] for a in (sa, ea)]
+                snaps.append(([t.clone() for t in tr._graphs._a[key][3]], levels))
         outs[graphs] = res
         torch.cuda.synchronize()
+        if graphs:
+            # every level of both encoders, replay after replay, against an eager pass over the same clouds - bit for bit (round 5: a memset
+            # node of the side-stream graph was not ordered before the kernel that combines into the zeroed buffer; the poses rarely showed it)
+            for (pts, *_), (statics, levels) in zip(frames, snaps):
+                for a, lv, cv in ((sa, levels[0], statics[1]), (ea, levels[1], statics[2])):
+                    ref, ws_ref = a.net.pts_encoder.forward(pts, return_intermediates=True, slot=0)
+                    for got, want in zip(lv, ws_ref["feat"]):
+                        assert torch.equal(got, want)
+                    assert torch.equal(cv, a.net.pose_score_net.cloud_embed(ref))
+                assert torch.equal(statics[0], pts.mean(dim=1))
     assert tr._graphs is None and len(outs[True]) == 4
     for a, b in zip(outs[True], outs[False]):
         for k in ("init_x", "pred_pose", "energy", "sorted_RTs", "average_sRT"):
