@@ -88,6 +88,12 @@ def make_cloud(i, n_pts=1024, force_few=None):
     p = p[vis]
     if p.shape[0] < 8:
         p = (_surface(rng, 0, 500)[0] * extent) + centre
+    return _through_the_camera(p, rng, few, n_pts)
+
+
+def _through_the_camera(p, rng, few, n_pts):
+    """Visible surface points [m,3] (camera frame, metres) -> what the reference's loader would hand over: projected with the REAL
+    intrinsics, snapped to pixels, depth quantised to 1 mm, one sample per pixel, back-projected, resampled to n_pts."""
     u = np.round(p[:, 0] / p[:, 2] * FX + CX).astype(np.int64)
     v = np.round(p[:, 1] / p[:, 2] * FY + CY).astype(np.int64)
     z_mm = np.round(p[:, 2] * 1000.0).astype(np.int64)
@@ -103,6 +109,137 @@ def make_cloud(i, n_pts=1024, force_few=None):
 
 def make_batch(B, start=0, n_pts=1024):
     return np.stack([make_cloud(start + i, n_pts) for i in range(B)], 0)
+
+
+# ------------------------------------------------------------------ clouds WITH a ground-truth pose (training / accuracy proxy)
+# NOCS categories (class id = index + 1, utils/sgpa_utils.py synset_names); bottle / bowl / can are symmetric about the object's y axis,
+# which is how the reference scores them (utils/metrics.py:107-113, sgpa_utils.py:548-560); camera / laptop / mug are built WITHOUT a
+# rotational symmetry (off-centre lens, lid shorter than the base, handle) so that their full rotation is identifiable from one view.
+CATEGORIES = ("bottle", "bowl", "camera", "can", "laptop", "mug")
+
+
+def _ring(rng, n, r0, r1, y0, y1, two_sided=False):
+    """Surface of revolution about y between (r0, y0) and (r1, y1) (cylinder, cone or disc), sampled uniformly in area."""
+    u = rng.uniform(size=n)
+    if r0 != r1:
+        rr = np.sqrt(u * (r1 * r1 - r0 * r0) + r0 * r0)  # area-uniform along a cone / annulus
+        s = (rr - r0) / (r1 - r0)
+    else:
+        rr, s = np.full(n, r0), u
+    th = rng.uniform(0, 2 * np.pi, n)
+    p = np.stack([rr * np.cos(th), y0 + s * (y1 - y0), rr * np.sin(th)], 1)
+    dr, dy = r1 - r0, y1 - y0
+    L = np.hypot(dr, dy)
+    nr, ny = dy / L, -dr / L  # outward for dy > 0; a disc (dy = 0) gets +-y
+    nrm = np.stack([nr * np.cos(th), np.full(n, ny), nr * np.sin(th)], 1)
+    if two_sided:
+        nrm = nrm * np.where(rng.uniform(size=(n, 1)) < 0.5, 1.0, -1.0)
+    return p, nrm
+
+
+def _pieces(rng, n, pieces):
+    """pieces: [(area weight, sampler(rng, m))] -> n points over all of them in proportion to their areas."""
+    w = np.array([a for a, _ in pieces], dtype=np.float64)
+    counts = rng.multinomial(n, w / w.sum())
+    out = [f(rng, int(m)) for (_, f), m in zip(pieces, counts) if m > 0]
+    return np.concatenate([o[0] for o in out], 0), np.concatenate([o[1] for o in out], 0)
+
+
+def _rect(rng, n, origin, eu, ev, normal, two_sided=False):
+    uv = rng.uniform(0, 1, (n, 2))
+    p = np.asarray(origin, dtype=np.float64) + uv[:, :1] * np.asarray(eu, dtype=np.float64) + uv[:, 1:] * np.asarray(ev, dtype=np.float64)
+    nrm = np.tile(np.asarray(normal, dtype=np.float64), (n, 1))
+    if two_sided:
+        nrm = nrm * np.where(rng.uniform(size=(n, 1)) < 0.5, 1.0, -1.0)
+    return p, nrm
+
+
+def _posed_surface(rng, cat, n):
+    """Object-frame points + normals of category `cat` (index into CATEGORIES); y is the object's up axis as in NOCS."""
+    cone = lambda r0, r1, y0, y1: np.pi * (r0 + r1) * np.hypot(r1 - r0, y1 - y0)
+    if cat == 0:    # bottle: body, shoulder, neck, cap, bottom - up and down differ
+        return _pieces(rng, n, [(cone(.25, .25, -.5, .15), lambda g, m: _ring(g, m, .25, .25, -.5, .15)),
+                                (cone(.25, .10, .15, .30), lambda g, m: _ring(g, m, .25, .10, .15, .30)),
+                                (cone(.10, .10, .30, .50), lambda g, m: _ring(g, m, .10, .10, .30, .50)),
+                                (cone(.10, 1e-3, .50, .50), lambda g, m: _ring(g, m, .10, 1e-3, .50, .50)),
+                                (cone(1e-3, .25, -.5, -.5), lambda g, m: _ring(g, m, 1e-3, .25, -.5, -.5))])
+    if cat == 1:    # bowl: hemisphere open towards +y, inside and outside visible
+        u = rng.uniform(0, 1, n)
+        th = rng.uniform(0, 2 * np.pi, n)
+        ph = np.arccos(u)
+        d = np.stack([np.sin(ph) * np.cos(th), -np.cos(ph), np.sin(ph) * np.sin(th)], 1)
+        return 0.5 * d, d * np.where(rng.uniform(size=(n, 1)) < 0.5, 1.0, -1.0)
+    if cat == 2:    # camera: box with an off-centre lens barrel on the +z face
+        ex, ey, ez = 0.5, 0.35, 0.3
+        faces = []
+        for ax, (a, b, c) in enumerate(((ex, ey, ez), (ey, ez, ex), (ez, ex, ey))):
+            for sgn in (1.0, -1.0):
+                o, eu, ev, nr = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+                i, j, k = ax, (ax + 1) % 3, (ax + 2) % 3
+                o[i], o[j], o[k] = sgn * a, -b, -c
+                eu[j], ev[k], nr[i] = 2 * b, 2 * c, sgn
+                faces.append((4 * b * c, (lambda o, eu, ev, nr: lambda g, m: _rect(g, m, o, eu, ev, nr))(o, eu, ev, nr)))
+
+        def lens(g, m, kind):
+            q, nq = _ring(g, m, .2, .2, ez, ez + .3) if kind == 0 else _ring(g, m, 1e-3, .2, ez + .3, ez + .3)
+            if kind == 1:
+                nq = -nq  # the cap of the barrel looks outwards (+ along the barrel)
+            # the barrel's axis is the object's z: (x, y, z) <- (x, z, y) of the ring, then the offset in the face
+            q, nq = q[:, [0, 2, 1]], nq[:, [0, 2, 1]]
+            q[:, 0] += 0.2
+            q[:, 1] -= 0.08
+            return q, nq
+        return _pieces(rng, n, faces + [(cone(.2, .2, 0, .3), lambda g, m: lens(g, m, 0)), (np.pi * .04, lambda g, m: lens(g, m, 1))])
+    if cat == 3:    # can: slightly tapered (top narrower), lids
+        return _pieces(rng, n, [(cone(.30, .24, -.5, .5), lambda g, m: _ring(g, m, .30, .24, -.5, .5)),
+                                (np.pi * .24 ** 2, lambda g, m: (lambda q: (q[0], -q[1]))(_ring(g, m, 1e-3, .24, .5, .5))),
+                                (np.pi * .30 ** 2, lambda g, m: _ring(g, m, 1e-3, .30, -.5, -.5))])
+    if cat == 4:    # laptop: base (1.0 x 0.7) and a shorter lid (1.0 x 0.5) hinged at the back, both thin (seen from either side)
+        return _pieces(rng, n, [(0.70, lambda g, m: _rect(g, m, [-.5, 0, -.35], [1, 0, 0], [0, 0, .7], [0, 1, 0], True)),
+                                (0.50, lambda g, m: _rect(g, m, [-.5, 0, -.35], [1, 0, 0], [0, .5, 0], [0, 0, 1], True))])
+    if cat == 5:    # mug: open cylinder (inside visible), bottom, handle (half a torus in the xy plane on the +x side)
+        def handle(g, m):
+            a = g.uniform(-np.pi / 2, np.pi / 2, m)   # along the handle
+            b = g.uniform(0, 2 * np.pi, m)            # around the tube
+            R0, r0 = 0.22, 0.05
+            c = np.stack([0.3 + R0 * np.cos(a), R0 * np.sin(a), np.zeros(m)], 1)
+            radial = np.stack([np.cos(a), np.sin(a), np.zeros(m)], 1)
+            nq = radial * np.cos(b)[:, None] + np.array([0, 0, 1.0]) * np.sin(b)[:, None]
+            return c + r0 * nq, nq
+        return _pieces(rng, n, [(cone(.3, .3, -.4, .4), lambda g, m: _ring(g, m, .3, .3, -.4, .4, True)),
+                                (np.pi * .09, lambda g, m: _ring(g, m, 1e-3, .3, -.4, -.4, True)),
+                                (np.pi * .22 * 2 * np.pi * .05, handle)])
+    raise ValueError(cat)
+
+
+def make_posed_cloud(i, n_pts=1024, cat=None):
+    """One REAL275-shaped cloud with its ground truth, seeded by its index: {'pts' [n_pts,3] f32 (camera frame, metres), 'R' [3,3],
+    't' [3] (object frame -> camera frame; the 9-D pose of the reference's 'rot_matrix' mode is [R[:,0], R[:,1], t],
+    datasets_genpose.py:692-695), 'cat' 0..5, 'scale'}.  Same camera model and resampling as make_cloud; 10 % of the instances have
+    fewer than 1024 distinct points."""
+    rng = np.random.default_rng([0x706F7365, i])
+    cat = int(rng.integers(0, len(CATEGORIES))) if cat is None else int(cat)
+    extent = rng.uniform(0.08, 0.30)
+    centre = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(0.5, 1.2)])
+    Rm = _rand_rot(rng)
+    few = bool(rng.uniform() < 0.1)
+    p, nrm = _posed_surface(rng, cat, int(rng.integers(100, 1023)) * 3 if few else 12000)
+    p = (p * extent) @ Rm.T + centre
+    vis = np.sum((nrm @ Rm.T) * (-p), axis=1) > 0  # camera at the origin
+    if vis.sum() >= 8:
+        p = p[vis]
+    return {"pts": _through_the_camera(p, rng, few, n_pts), "R": Rm, "t": centre, "cat": cat, "scale": extent}
+
+
+def posed_batch(indices, n_pts=1024):
+    """-> dict of arrays with leading dim len(indices): pts f32, gt_pose [.,9] f32, R, t f64, cat i64, scale, handle_visibility (1)."""
+    items = [make_posed_cloud(int(i), n_pts) for i in indices]
+    R = np.stack([it["R"] for it in items], 0)
+    t = np.stack([it["t"] for it in items], 0)
+    return {"pts": np.stack([it["pts"] for it in items], 0), "R": R, "t": t,
+            "gt_pose": np.concatenate([R[:, :, 0], R[:, :, 1], t], axis=1).astype(np.float32),
+            "cat": np.array([it["cat"] for it in items], dtype=np.int64), "scale": np.array([it["scale"] for it in items]),
+            "handle_visibility": np.ones(len(items), dtype=np.int64)}
 
 
 def smoke_batch(B, seed=0, n_pts=1024):
