@@ -107,7 +107,81 @@ def self_launch(args):
     env["GP_BENCH_LAUNCH"] = "self"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    got_line = False
+    for ln in p.stdout:  # relay; remember whether rank 0 printed its JSON line
+        got_line = got_line or ln.startswith("{")
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = p.wait()
+    if not got_line:
+        print(json.dumps({"metric": "poses/sec (1024-pt cloud, 50 cand x 100 SDE steps)", "value": None, "unit": "poses/s", "n_gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "error": f"torch.distributed.run exited with code {rc} and rank 0 printed no line",
+                          "launch": {"mode": "self", "world_size_env": args.gpus}}), flush=True)
+    return rc
+
+
+class _StartGuard:
+    """The first multi-rank start must never end without a parseable line: whatever goes wrong between the launcher and the first
+    completed collective (a rank that dies, a rendezvous that never completes, RCCL hanging in its first all-reduce, the launcher
+    terminating the survivors of a failed peer), rank 0 prints ONE JSON line with an "error" field, the backend and what torch sees of
+    the box - and every rank leaves, so that the launcher returns instead of sitting in the driver's time limit."""
+
+    def __init__(self, args, rank, world):
+        self.args, self.rank, self.world, self.backend, self.done, self.timer = args, rank, world, None, False, None
+
+    def line(self, msg):
+        import torch
+        try:
+            ndev = torch.cuda.device_count()
+        except Exception:  # noqa: BLE001
+            ndev = None
+        return json.dumps({"metric": "poses/sec (1024-pt cloud, 50 cand x 100 SDE steps)", "value": None, "unit": "poses/s", "n_gpus": self.args.gpus,
+                           "steps": self.args.steps, "warmup": self.args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "error": msg,
+                           "launch": {"mode": os.environ.get("GP_BENCH_LAUNCH", "torch.distributed.run"), "world_size_env": self.world,
+                                      "backend": self.backend, "device_count": ndev, "rank": self.rank,
+                                      "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"},
+                           "roofline": None, "cpu_baseline": None})
+
+    def fail(self, msg, code=3):
+        if not self.done:
+            self.done = True
+            if self.rank == 0:
+                print(self.line(msg), flush=True)
+            else:
+                print(f"[bench.py rank {self.rank}] {msg}", file=sys.stderr, flush=True)
+        os._exit(code)  # no atexit handlers, no destructors of a half-built process group
+
+    def arm(self, seconds, what):
+        import threading
+        self.disarm()
+        self.timer = threading.Timer(seconds, lambda: self.fail(f"{what}: no progress for {seconds:.0f} s"))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def watch_sigterm(self):
+        """SIGTERM from the launcher (it terminates the survivors when a peer rank has failed) must produce the line even while the main
+        thread sits inside a C++ rendezvous or collective, where a Python-level signal handler would not run: the C-level handler writes
+        the signal number to a wake-up pipe at once and a watcher thread takes it from there."""
+        import signal
+        import threading
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)  # (a Python-level handler must exist for the wake-up write to happen)
+        signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+
+        def watch():
+            while True:
+                b = os.read(r, 1)
+                if b and b[0] == signal.SIGTERM:
+                    self.fail("terminated by the launcher before the result line (a peer rank failed?)", code=4)
+        threading.Thread(target=watch, daemon=True).start()
 
 
 def main():
@@ -119,25 +193,49 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    guard = _StartGuard(args, rank, world)
     if world != args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}")
+        guard.fail(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}", code=2)
+    if os.environ.get("GP_BENCH_KILL_RANK") == str(rank):  # rehearsal of a rank that dies before the rendezvous (tests/test_gpu_bench.py)
+        os._exit(17)
     # GP_BENCH_ONE_DEVICE=1 (self-test on a 1-GPU box): every rank uses cuda:0 and the collectives run on gloo
     one_dev = os.environ.get("GP_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        guard.fail(f"LOCAL_RANK {local_rank} but torch sees {torch.cuda.device_count()} device(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     backend = None
     if world > 1 or os.environ.get("GP_BENCH_FORCE_DIST") == "1" or os.environ.get("GP_BENCH_LAUNCH") == "self":  # GP_BENCH_FORCE_DIST: exercise RCCL with one rank (self-test)
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = "gloo" if one_dev else "nccl"  # "nccl" = RCCL on ROCm
-        if one_dev:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = guard.backend = "gloo" if one_dev else "nccl"  # "nccl" = RCCL on ROCm
+        limit = float(os.environ.get("GP_BENCH_START_TIMEOUT", "180"))
+        guard.watch_sigterm()
+        guard.arm(limit + 30, f"process group start ({backend}, {world} ranks)")
+        try:
+            to = datetime.timedelta(seconds=limit)
+            if one_dev:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=to)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=to)
+            # the first collective (RCCL builds its rings here): every rank contributes 1, every rank must see the world size
+            one = torch.ones(1, device="cpu" if one_dev else dev)
+            dist.all_reduce(one)
+            if not one_dev:
+                torch.cuda.synchronize()
+            seen = int(round(float(one.item())))
+            if seen != world or dist.get_world_size() != world:
+                guard.fail(f"first all-reduce saw {seen} rank(s), process group reports {dist.get_world_size()}, expected {world}")
+        except SystemExit:
+            raise
+        except BaseException as exc:  # noqa: BLE001
+            guard.fail(f"process group start failed on {backend}: {type(exc).__name__}: {exc}")
+        guard.disarm()
 
     from genpose_amd import reward, synth
     from genpose_amd.config import get_config
@@ -149,6 +247,7 @@ def main():
         return
     if args.tracking:
         tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend)
+        guard.done = True
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -295,11 +394,7 @@ def main():
             side["drop_in_eval_single"] = drop_in_leg(torch, str(dev), K)
             side["config0_single_object"] = config0_leg(torch, str(dev))
             side["energy_model_pc_step"] = energy_model_leg(torch, str(dev), B, K, G)
-            for name, too in (("encoder_split_bf16", False), ("encoder_and_sampler_split_bf16", True)):
-                try:  # optional, exploratory legs must never cost the line
-                    side[name] = split_bf16_leg(torch, score_agent, pool, B, K, n, G, str(dev), too)
-                except Exception as exc:  # noqa: BLE001
-                    side[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            # (the two opt-in split-bf16 legs are NOT part of the default run since round 6: frozen, `--only-split-bf16` prints them)
         if not args.no_cpu_baseline:
             side["cpu_baseline"] = run_cpu_baseline(torch, args, K, n)
 
@@ -334,7 +429,9 @@ def main():
             "roofline": roofline, "cpu_baseline": side.pop("cpu_baseline", None),
         }
         line.update(side)
+        guard.done = True
         print(json.dumps(line), flush=True)
+    guard.done = True
     if dist is not None:
         dist.destroy_process_group()
 
@@ -419,13 +516,17 @@ def tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend):
         for f in range(8):
             tr.step(frames_1[f % nfr], names_1, gt_1)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nf = 60
-        for f in range(nf):
-            tr.step(frames_1[(8 + f) % nfr], names_1, gt_1)
-        torch.cuda.synchronize()
-        dt1 = (time.perf_counter() - t0) / nf
-        single = {"ms_per_frame": round(dt1 * 1e3, 3), "frames_per_s": round(1.0 / dt1, 1), "objects_per_frame": n_obj, "nfev": int(sa.net.last_sampler.last_stats["nfev"]) ,
+        nf, per = 60, []
+        for rep in range(7):
+            t0 = time.perf_counter()
+            for f in range(nf):
+                tr.step(frames_1[(8 + rep * nf + f) % nfr], names_1, gt_1)
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / nf)
+        dt1 = statistics.median(per)
+        single = {"ms_per_frame": round(dt1 * 1e3, 3), "ms_per_frame_min": round(min(per) * 1e3, 3), "ms_per_frame_max": round(max(per) * 1e3, 3),
+                  "repeats": len(per), "frames_per_repeat": nf, "statistic": "median of the repeats",
+                  "frames_per_s": round(1.0 / dt1, 1), "objects_per_frame": n_obj, "nfev": int(sa.net.last_sampler.last_stats["nfev"]),
                   "workload": "one sequence, one TrackingRunner.step per frame"}
     if rank == 0:
         value = world * S * n_obj * args.steps / elapsed
@@ -773,13 +874,17 @@ def config0_leg(torch, dev):
         for j in range(6):
             call(pool[j % 4])
         torch.cuda.synchronize()
-        nb = 40
-        t0 = time.perf_counter()
-        for j in range(nb):
-            call(pool[j % 4])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / nb
-        out[name] = {"ms_per_call": round(dt * 1e3, 3), "poses_per_s": round(B / dt, 1)}
+        nb, reps = 30, 7
+        per = []
+        for _ in range(reps):  # a latency figure moves by ~20 % between sessions and by several % inside one: median AND range are reported
+            t0 = time.perf_counter()
+            for j in range(nb):
+                call(pool[j % 4])
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / nb)
+        dt = statistics.median(per)
+        out[name] = {"ms_per_call": round(dt * 1e3, 3), "ms_per_call_min": round(min(per) * 1e3, 3), "ms_per_call_max": round(max(per) * 1e3, 3),
+                     "repeats": reps, "calls_per_repeat": nb, "statistic": "median of the repeats", "poses_per_s": round(B / dt, 1)}
         if sampler == "ode":
             out[name]["nfev"] = int(sa.net.last_sampler.last_stats["nfev"])
     return out

@@ -12,6 +12,8 @@ SO_PATH = os.environ.get("GENPOSE_HIP_LIB") or os.path.join(_HERE, "lib", "libge
 
 c_int, c_float, c_void_p, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 P = c_void_p
+PLAN_SHARED = 0x200     # GP_PLAN_SHARED: the RK45 driver's shared-chunk plan (16 | or 48 |), see include/genpose_hip.h
+PLAN_FLAGS = 0x300
 PLAN_HEADSPLIT = 0x100  # GP_PLAN_HEADSPLIT (include/genpose_hip.h): OR-ed onto a 16-row tile plan = three workgroups per tile, one head each
 
 
@@ -77,6 +79,8 @@ SIGNATURES = {
     "gp_rk45_phase_grouped": [c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5 + [c_int, c_int, P, P],
     "gp_rk45_plan_rows": [c_int, c_int, c_int, c_int],
     "gp_plan_headsplit_pays": [c_int],
+    "gp_rk45_plan_rows_unshared": [c_int, c_int, c_int, c_int],
+    "gp_rk45_partials_count": [c_int, c_int, c_int, c_int, c_int],
     "gp_rk45_phase_model": [c_int, c_int, P, c_int, c_int, c_int, c_int, NETP, P, P, P, P, P, P, P, P, P, c_int] + [ctypes.c_double] * 5
                            + [c_int, c_int, P, P, c_int, P],
     "gp_rk45_set_dense_grouped": [c_int, P, P, c_int, P, P],
@@ -84,6 +88,7 @@ SIGNATURES = {
                             + [c_int, c_int, P, P],
     "gp_time_embed_strided": [c_int, c_int, c_int64, NETP, P, P, P],
     "gp_rank_aggregate": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
+    "gp_rank_aggregate_rt": [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P],
     "gp_pose9_to_rt": [c_int, c_int, P, P, P],
     "gp_quat_trans_to_rt": [c_int, P, P, P],
 }

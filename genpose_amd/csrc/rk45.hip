@@ -54,6 +54,10 @@ struct Rk45State {
     double stage_g2[8];    // f64 g(t)^2 of the PF-ODE right-hand side (sde.py:20-24 on a 0-dim f64 tensor)
     double log_t[512], log_h[512], log_err[512];  // per attempt (diagnostics / parity tests)
     int log_acc[512];
+    // shared-chunk plan (GP_PLAN_SHARED): progress word of every shared 16-row chunk, 8 * attempt + stages completed (appended: the
+    // offsets gp_rk45_state_layout exports do not move)
+    int xflags[64];
+    int xfail;  // a bounded wait of the shared-chunk plan ran out: the controller ends the solve with status -2
 };
 
 __device__ __forceinline__ void set_stage(Rk45State *st, int slot, double t) {
@@ -127,6 +131,24 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     return s;
 }
 
+// Loads / stores of state the shared-chunk plan hands from one workgroup to another INSIDE a launch (XWG): relaxed atomics at agent scope,
+// i.e. sc1 accesses that are served by the memory side of the L2s - no stale line of another XCD's L2 or of a CU's vector cache can
+// answer them, and no cache has to be invalidated (an acquire fence at agent scope would drop the XCD's cached weights with it).
+template <bool XWG>
+__device__ __forceinline__ double ldx(const double *p) {
+    if constexpr (XWG)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        return *p;
+}
+template <bool XWG>
+__device__ __forceinline__ void stx(double *p, double v) {
+    if constexpr (XWG)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
 // Fused stage kernel.  STAGE 1..6: Runge-Kutta stage;  STAGE 0: f0 = fun(t0, y0) (+ d0,d1 partials);
 // STAGE 7: f1 = fun(t0 + h0*dir, y0 + h0*dir*f0) (+ d2 partial).
 // One stage for the workgroup's tile.  Returns false when the workgroup has nothing to do (padding workgroup, finished solve).
@@ -134,14 +156,17 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 // components - it computes the stage input of all nine (the network needs them; element-local arithmetic, identical in the three
 // workgroups of a tile), and commits / stores / sums only its own.  What a stage reads of earlier stages (K_q of all nine components)
 // was written by other workgroups: the stages of an attempt are separate launches under this plan.
-template <int P, int STAGE, int MODEL, bool SPLIT = false>
-__device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_scorenet &net, float *lds, double *sh) {
+// XWG / wg_tile / wg_part (shared-chunk plan): the tile and the partial-sum slot come from the caller instead of blockIdx.x, and XWG marks a
+// tile whose state other workgroups of the same launch have written or will read (ldx / stx above).
+template <int P, int STAGE, int MODEL, bool SPLIT = false, bool XWG = false>
+__device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_scorenet &net, float *lds, double *sh, int wg_tile = -1, int wg_part = -1) {
     static_assert(MODEL == 0 || P == gp_bwd::DP, "the backward pass runs on 16-row tiles");
     static_assert(!SPLIT || (MODEL == 0 && P == 16), "head-split: score model, 16-row tiles");
     using L = TrunkLds<P, OdeModel<MODEL>::BWD>;
     constexpr int NC = OdeModel<MODEL>::NC;
     const int tid = threadIdx.x;
-    const int tile = SPLIT ? blockIdx.x / 3 : blockIdx.x, hsel = SPLIT ? blockIdx.x - 3 * tile : 0;
+    const int wgi = wg_tile >= 0 ? wg_tile : (int)blockIdx.x, part = wg_part >= 0 ? wg_part : (int)blockIdx.x;
+    const int tile = SPLIT ? wgi / 3 : wgi, hsel = SPLIT ? wgi - 3 * tile : 0;
     auto owned = [&](int j) { return !SPLIT || j / 3 == hsel; };
     int grp, row0, rend;
     ode_block<P>(a, tile, grp, row0, rend);
@@ -168,21 +193,21 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
         const int r = live ? row0 + rr : rend - 1;  // rows past the end: clamped duplicates (computed, never stored)
         const size_t ge = (size_t)r * NC + j;
         const bool commit = STAGE == 1 && st->last_accepted;
-        double yv = commit ? a.ynew[ge] : a.y[ge];
+        double yv = commit ? ldx<XWG>(a.ynew + ge) : ldx<XWG>(a.y + ge);
         if (commit && live && owned(j)) {
             // commit the previous accepted step for this element (element-local: no other thread touches it)
-            a.y[ge] = yv;
-            a.K[ge] = a.K[6 * n + ge];
+            stx<XWG>(a.y + ge, yv);
+            stx<XWG>(a.K + ge, ldx<XWG>(a.K + 6 * n + ge));
         }
         if (STAGE >= 1 && STAGE <= 6) {
             double dy = 0.0;
 #pragma unroll
             for (int q = 0; q < STAGE; ++q) {
-                const double kq = (q == 0 && commit) ? a.K[6 * n + ge] : a.K[(size_t)q * n + ge];
+                const double kq = (q == 0 && commit) ? ldx<XWG>(a.K + 6 * n + ge) : ldx<XWG>(a.K + (size_t)q * n + ge);
                 dy += kq * DP_A[STAGE][q];
             }
             yv = yv + dy * h;  // rk.py: dy = dot(K[:s].T, a[:s]) * h ; y + dy   (stage 6: y + h * dot(K[:-1].T, B))
-            if (STAGE == 6 && live && owned(j)) a.ynew[ge] = yv;
+            if (STAGE == 6 && live && owned(j)) stx<XWG>(a.ynew + ge, yv);
         } else if (STAGE == 7) {
             yv = yv + st->h0 * st->direction * a.K[ge];  // common.py: y1 = y0 + h0 * direction * f0
         }
@@ -208,7 +233,7 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
         const size_t ge = (size_t)(row0 + r) * NC + j;
         const float rhs = MODEL == 0 ? F[r * ldf + j] / (sigma + 1e-7f) : F[r * ldf + j];  // score component (j = 9: divergence estimate)
         const double kv = 0.0 - (0.5 * g2) * (double)rhs;  // drift - 0.5 * g^2 * score (samplers.py:198; :83-86 for the log-density)
-        Kout[ge] = kv;
+        stx<XWG>(Kout + ge, kv);
         if (STAGE == 0) {
             const double yv = a.y[ge];
             const double sc = st->atol + fabs(yv) * st->rtol;
@@ -221,20 +246,20 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
         } else if (STAGE == 6) {
             double er = 0.0;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) er += a.K[(size_t)q * n + ge] * DP_E[q];
+            for (int q = 0; q < 6; ++q) er += ldx<XWG>(a.K + (size_t)q * n + ge) * DP_E[q];
             er += kv * DP_E[6];
             er *= h;  // rk.py: dot(K.T, E) * h
-            const double yo = a.y[ge], yn = a.ynew[ge];
+            const double yo = ldx<XWG>(a.y + ge), yn = ldx<XWG>(a.ynew + ge);
             const double sc = st->atol + fmax(fabs(yo), fabs(yn)) * st->rtol;
             acc0 += (er / sc) * (er / sc);
         }
     }
     if (STAGE == 0 || STAGE == 6 || STAGE == 7) {
         const double s0 = block_sum(acc0, sh);
-        if (tid == 0) a.partials[blockIdx.x] = s0;
+        if (tid == 0) a.partials[part] = s0;
         if (STAGE == 0) {
             const double s1 = block_sum(acc1, sh);
-            if (tid == 0) a.partials[a.nblocks * a.hsplit + blockIdx.x] = s1;
+            if (tid == 0) a.partials[a.nblocks * a.hsplit + part] = s1;
         }
     }
     return true;
@@ -267,6 +292,86 @@ __global__ __launch_bounds__(TrunkCfg<P>::NT) void rk45_attempt_kernel(OdeArgs a
     rk45_stage_body<P, 5, MODEL>(a, net, lds, sh);
     __syncthreads();
     rk45_stage_body<P, 6, MODEL>(a, net, lds, sh);
+}
+
+// The SHARED-CHUNK plan (GP_PLAN_SHARED, round 6; score model, one group): an attempt as ONE launch of one workgroup per CU in which the
+// 16-row chunks that do not divide over the CUs are shared ACROSS STAGES instead of costing every stage a fourth round.
+//   12 800 rows (scripts/eval_single.sh: 256 clouds x 50 candidates) = 800 chunks on 256 CUs: 3 whole chunks per CU and 32 left over.
+//   Per-stage launches are bound by the busiest CU - 4 chunks - whatever the tile shape (72 us per stage on 64-row tiles, 200 CUs busy).
+//   Here workgroup w owns rows [w PW, (w + 1) PW) (PW = 16 x whole chunks per CU) for all six stages (row-local, as rk45_attempt_kernel),
+//   and the 6 x 32 (chunk, stage) units of the left-over chunks are dealt out one per workgroup: workgroup 6 j + s - 1 evaluates stage s
+//   of shared chunk j as a 16-row tile just before its own stage s.  The busiest CU then does 6 x PW rows + ONE 16-row tile per attempt
+//   instead of 6 x (PW + 16) rows.
+// A shared chunk's stages run on six different CUs inside one launch: its state (y, y_new, K) moves through the memory side of the L2s
+// (ldx / stx) and a progress word per chunk orders the stages: 8 x attempt + s once stage s is complete.  The producer of stage s - 1 ran
+// it one whole tile pass earlier in its own sequence than the consumer needs it, so the wait is a formality - and it is BOUNDED: a
+// consumer that never sees its word fails the solve (status -2) instead of hanging the device.  Workgroups wait only on lower-numbered
+// workgroups, which the dispatcher starts first.
+__device__ __forceinline__ bool shared_chunk_wait(int *flag, int want, Rk45State *st, double *sh) {
+    int *ok = reinterpret_cast<int *>(sh);
+    if (threadIdx.x == 0) {
+        int it = 0, got = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (got != want && ++it < (1 << 18) && __hip_atomic_load(&st->xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            got = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *ok = got == want;
+        // (not st->status: the other workgroups read it while they run; the controller kernel turns xfail into status -2)
+        if (got != want) __hip_atomic_store(&st->xfail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool r = *ok != 0;
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ void shared_chunk_signal(int *flag, int value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's stores of the chunk's state have completed at agent scope
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int PW>
+__global__ __launch_bounds__(TrunkCfg<PW>::NT) void rk45_attempt_shared_kernel(OdeArgs a, gp_scorenet net, int nshared) {
+    static_assert(TrunkCfg<PW>::NT == TrunkCfg<16>::NT, "own tile and shared 16-row tile run on the same waves");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ double sh[8];
+    Rk45State *st = a.st;
+    if (st->status != 0) return;
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    const int xj = wg / 6, xs = wg - 6 * xj + 1;       // this workgroup's shared unit: stage xs of shared chunk xj
+    const bool has_x = xj < nshared;
+    const int xtile = (nwg * PW) / 16 + xj;            // the shared chunk as a 16-row tile of the whole batch
+    const int xpart = nwg + xj;                        // its slot among the partial sums of the error norm
+    const int epoch = 8 * st->n_attempts;              // (written by the controller kernel, between attempts)
+    int *flag = st->xflags + xj;
+    bool alive = true;
+#define GP_SHARED_UNIT(S)                                                                                   \
+    if (has_x && xs == S && alive) {                                                                        \
+        if (S > 1) alive = shared_chunk_wait(flag, epoch + S - 1, st, sh);                                  \
+        if (alive) {                                                                                        \
+            rk45_stage_body<16, S, 0, false, true>(a, net, lds, sh, xtile, xpart);                          \
+            shared_chunk_signal(flag, epoch + S);                                                           \
+            __syncthreads();                                                                                \
+        }                                                                                                   \
+    }
+    GP_SHARED_UNIT(1)
+    rk45_stage_body<PW, 1, 0>(a, net, lds, sh, wg, wg);
+    __syncthreads();
+    GP_SHARED_UNIT(2)
+    rk45_stage_body<PW, 2, 0>(a, net, lds, sh, wg, wg);
+    __syncthreads();
+    GP_SHARED_UNIT(3)
+    rk45_stage_body<PW, 3, 0>(a, net, lds, sh, wg, wg);
+    __syncthreads();
+    GP_SHARED_UNIT(4)
+    rk45_stage_body<PW, 4, 0>(a, net, lds, sh, wg, wg);
+    __syncthreads();
+    GP_SHARED_UNIT(5)
+    rk45_stage_body<PW, 5, 0>(a, net, lds, sh, wg, wg);
+    __syncthreads();
+    GP_SHARED_UNIT(6)
+    rk45_stage_body<PW, 6, 0>(a, net, lds, sh, wg, wg);
+#undef GP_SHARED_UNIT
 }
 
 // The same stage in the CHAIN form of the trunk (trunk_chain.h; score model, equal groups, launches of ~32 000 rows and more): a wave
@@ -546,6 +651,10 @@ __global__ __launch_bounds__(256) void rk45_decide_kernel(OdeArgs a, int mode) {
         publish_attempt(st);
     } else {
         if (st->status != 0) return;
+        if (st->xfail) {  // shared-chunk plan: a stage never saw its predecessor (bounded wait) - fail the solve, do not integrate garbage
+            if (threadIdx.x == 0) st->status = -2;
+            return;
+        }
         const double s0 = a.ext_sums ? a.ext_sums[blockIdx.x] : sum_partials(part, nblk, sh);
         if (threadIdx.x == 0) {
             const double err = sqrt(s0) / sqrt(nn);
@@ -727,6 +836,8 @@ __device__ void reset_state(Rk45State *st, double t0, double t_bound, double rto
     st->status = 0, st->last_accepted = 0, st->step_rejected = 0;
     st->n_attempts = 0, st->n_accepted = 0, st->nfev = 0, st->traj_cap = traj_cap;
     st->n_eval = 0, st->next_eval = 0, st->emit_begin = 0, st->emit_end = 0, st->t_old = t0, st->t_eval = nullptr;
+    for (int i = 0; i < 64; ++i) st->xflags[i] = 0;
+    st->xfail = 0;
     // the very first evaluation gets a python-float t: sde_coeff(torch.tensor(t)) is f32 there;
     // the f64 formula differs by <= 1e-7 relative - documented deviation.
     for (int i = 0; i < 8; ++i) st->stage_t[i] = 0.f, st->stage_sigma[i] = 1.f, st->stage_g2[i] = 0.0;
@@ -889,6 +1000,38 @@ static int rk45_phase_impl(int phase, OdeArgs &a, const gp_scorenet *net, double
     return gp_launch_status();
 }
 
+// Shared-chunk plan: which launches of `nrows` rows it serves, and its geometry.  T 16-row chunks on C CUs: `whole` = T / C chunks per
+// workgroup (1 or 3: the 16- and 48-row tiles run on four waves like the shared 16-row tile), rem = T % C shared chunks, 6 rem <= C units.
+struct SharedPlan {
+    int pw, nwg, nshared;
+};
+static inline bool shared_plan(int nrows, int kcand, SharedPlan *sp) {
+    const int C = gp_num_cus(), T = (nrows + 15) / 16;
+    const int whole = T / C, rem = T % C;
+    if ((whole != 1 && whole != 3) || rem == 0 || 6 * rem > C || rem > 64 || kcand < 24) return false;  // (k >= 24: a 48-row tile spans <= 3 clouds)
+    if (sp) sp->pw = 16 * whole, sp->nwg = C, sp->nshared = rem;
+    return true;
+}
+// One attempt under it: the attempt kernel, the controller over the C + rem partial sums, the next attempt's time embeddings, the record.
+template <int PW>
+static int rk45_attempt_shared(const OdeArgs &a0, const SharedPlan &sp, const gp_scorenet *net, double *traj, hipStream_t st) {
+    const size_t lds = trunk_lds_bytes<PW>() > trunk_lds_bytes<16>() ? trunk_lds_bytes<PW>() : trunk_lds_bytes<16>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (set_lds_attr(rk45_attempt_shared_kernel<PW>, lds)) return GP_ELAUNCH;
+        attr_done = true;
+    }
+    OdeArgs a = a0;
+    a.hsplit = 1, a.bpg = 1 << 30, a.nblocks = sp.nwg + sp.nshared;  // one group: every tile belongs to group 0
+    hipLaunchKernelGGL((rk45_attempt_shared_kernel<PW>), dim3(sp.nwg), dim3(TrunkCfg<PW>::NT), lds, st, a, *net, sp.nshared);
+    OdeArgs ad = a;
+    ad.bpg = ad.nblocks;  // the controller sums the group's C + rem partials
+    hipLaunchKernelGGL(rk45_decide_kernel, dim3(1), dim3(256), 0, st, ad, 2);
+    hipLaunchKernelGGL((rk45_embed_kernel<64, 1>), dim3(6, 1, 3), dim3(256), 0, st, a.st, 1, *net, a.tvec);
+    if (traj) hipLaunchKernelGGL(rk45_record_kernel, dim3(64, 1), dim3(256), 0, st, ad);
+    return gp_launch_status();
+}
+
 extern "C" {
 
 int64_t gp_rk45_state_bytes(void) { return (int64_t)sizeof(Rk45State); }
@@ -935,7 +1078,9 @@ static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *pro
     if (model < 0 || model > 2 || (model == 2 && !probe)) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
     // launch plan of the stage kernels (score_trunk.h: score_plan_rows): 16 / 32-row tiles or the 128-row chain form; plan != 0 forces one
-    if (plan == 0) plan = model == 0 ? score_plan_latency(ngroups * rg, ngroups > 1 ? rg : 0, k) : score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    // plan = 0: a WHOLE-tile plan (one partial sum per tile).  The head-split and shared-chunk plans keep more partial sums and are taken
+    // only when the caller asks for them by name - gp_rk45_plan_rows() recommends, gp_rk45_partials_count() sizes the buffer.
+    if (plan == 0) plan = model == 0 ? score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k) : score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
     if (plan < 0) return GP_EINVAL;
     const int P = plan & ~GP_PLAN_HEADSPLIT;
     a->hsplit = (plan & GP_PLAN_HEADSPLIT) ? 3 : 1;
@@ -969,14 +1114,31 @@ static int ode_args(OdeArgs *a, int *tile, int plan, int model, const float *pro
  * launch; a finished group's workgroups exit at once.  state: ngroups * gp_rk45_state_bytes(); tvec [ngroups][8][768];
  * partials [3][nblocks], nblocks = ngroups * ceil(rows_per_group / rows per workgroup).  plan (include/genpose_hip.h): rows per workgroup
  * of the stage kernels - 16 / 32 / 64 = tile form (models 1 and 2: 16 only), 128 = the chain form of the trunk (EVERY model since round 4:
- * with plan = 0, gp_rk45_plan_rows() also picks it for models 1 and 2 from ~24 600 rows, trunk_chain_vjp.h), 0 = pick.  A partials
- * buffer sized for 16-row tiles (gp_pc_tile_rows) is an upper bound for every model and every plan. */
+ * gp_rk45_plan_rows() also picks it for models 1 and 2 from ~24 600 rows, trunk_chain_vjp.h), 0 = pick a whole-tile plan.  `partials`
+ * holds gp_rk45_partials_count(model, plan, ...) doubles; a buffer of 3 x (16-row tiles) doubles is enough for every WHOLE-tile plan
+ * (plan = 0 included), NOT for 16 | GP_PLAN_HEADSPLIT (three sums per tile) - which is why plan = 0 never picks that one. */
 int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
                         double *x_out, double *ext_sums, int ext_rows_per_group, gp_stream_t s) {
     OdeArgs a;
     int P = 0;
+    if (plan > 0 && (plan & GP_PLAN_SHARED)) {
+        // shared-chunk plan: the attempts run on it; the two initial evaluations, the denoising evaluation and the bookkeeping phases
+        // run on the whole-tile plan of the same launch size
+        SharedPlan sp;
+        if (model != 0 || ngroups != 1 || ext_sums || nclouds_per_group <= 0 || k <= 0 || !shared_plan(nclouds_per_group * k, k, &sp) ||
+            (plan & ~GP_PLAN_SHARED) != sp.pw)
+            return GP_EINVAL;
+        const int base = score_plan_rows(nclouds_per_group * k, 0, k);
+        if (base < 0) return GP_EINVAL;
+        if (phase != 3)
+            return gp_rk45_phase_model(model, base, probe, phase, ngroups, nclouds_per_group, k, net, cvec, tvec, centre, state, y, ynew, K, partials, traj, traj_cap,
+                                       t0, t_bound, rtol, atol, denoise_scale, do_denoise, nstates, x_out, ext_sums, ext_rows_per_group, s);
+        if (ode_args(&a, &P, base, model, probe, ngroups, nclouds_per_group, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr) != GP_OK || !net)
+            return GP_EINVAL;
+        return sp.pw == 48 ? rk45_attempt_shared<48>(a, sp, net, traj, (hipStream_t)s) : rk45_attempt_shared<16>(a, sp, net, traj, (hipStream_t)s);
+    }
     int rc = ode_args(&a, &P, plan, model, probe, ngroups, nclouds_per_group, k, cvec, tvec, centre, state, y, ynew, K, partials, traj, nullptr);
     if (rc != GP_OK || !net) return GP_EINVAL;
     if (ext_sums && ext_rows_per_group < a.rows_per_group) return GP_EINVAL;
@@ -1003,7 +1165,36 @@ int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k) {
     if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || model < 0 || model > 2) return GP_EINVAL;
     const int rg = nclouds_per_group * k;
     if (model != 0) return score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    SharedPlan sp;
+    if (ngroups == 1 && shared_plan(rg, k, &sp)) return sp.pw | GP_PLAN_SHARED;  // a few chunks more than whole rounds of the CUs
     return score_plan_latency(ngroups * rg, ngroups > 1 ? rg : 0, k);
+}
+
+/* gp_rk45_plan_rows without the shared-chunk plan (a batch sharded over several GPUs: its controller runs on all-reduced per-group sums) */
+int gp_rk45_plan_rows_unshared(int model, int ngroups, int nclouds_per_group, int k) {
+    if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || model < 0 || model > 2) return GP_EINVAL;
+    const int rg = nclouds_per_group * k;
+    if (model != 0) return score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    return score_plan_latency(ngroups * rg, ngroups > 1 ? rg : 0, k);
+}
+
+/* Doubles the `partials` buffer of gp_rk45_phase_model must hold under `plan` (0 = what plan 0 resolves to), every phase included. */
+int gp_rk45_partials_count(int model, int plan, int ngroups, int nclouds_per_group, int k) {
+    if (ngroups <= 0 || nclouds_per_group <= 0 || k <= 0 || model < 0 || model > 2) return GP_EINVAL;
+    const int rg = nclouds_per_group * k;
+    auto whole = [&](int p) { return 3 * ngroups * ((rg + p - 1) / p); };
+    if (plan == 0) plan = model == 0 ? score_plan_rows(ngroups * rg, ngroups > 1 ? rg : 0, k) : score_plan_rows_vjp(ngroups * rg, ngroups > 1 ? rg : 0, k);
+    if (plan < 0) return GP_EINVAL;
+    if (plan & GP_PLAN_SHARED) {
+        SharedPlan sp;
+        if (model != 0 || ngroups != 1 || !shared_plan(rg, k, &sp) || (plan & ~GP_PLAN_SHARED) != sp.pw) return GP_EINVAL;
+        const int base = score_plan_rows(rg, 0, k);
+        const int a = whole(base), b = 3 * (sp.nwg + sp.nshared);
+        return a > b ? a : b;
+    }
+    const int P = plan & ~GP_PLAN_HEADSPLIT;
+    if (P != 16 && P != 32 && P != 64 && P != 128) return GP_EINVAL;
+    return whole(P) * ((plan & GP_PLAN_HEADSPLIT) ? 3 : 1);
 }
 
 int gp_plan_headsplit_pays(int ntiles16) { return headsplit_pays(ntiles16) ? 1 : 0; }

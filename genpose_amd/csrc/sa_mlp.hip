@@ -142,15 +142,20 @@ __global__ __launch_bounds__(256) void sa_mlp_kernel(SAArgs a) {
     __syncthreads();
     dense_to_lds<P, true>(Bf, ldb, a.w2, a.b2, a.c1, a.c2, A, lda);
     __syncthreads();
+    // channel split (gridDim.z workgroups per row tile, launch<P> on small GroupAll batches): every workgroup has computed layers 1-2 for
+    // its rows and takes its share of the last layer's output chunks - same MFMA order per output as the unsplit launch, bit for bit
+    const int NC3 = gp_round16(a.c3) / 16, per = (NC3 + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int nc_lo = (int)blockIdx.z * per, nc_hi = nc_lo + per < NC3 ? nc_lo + per : NC3;
+    if (nc_lo >= nc_hi) return;
     // a wave must own whole neighbourhoods for the in-register max: >= ns points per wave (GroupAll: any split, atomics combine)
-    const int wn = pick_wn(gp_round16(a.c3) / 16, P, a.groupall ? 16 : a.ns);
+    const int wn = pick_wn(nc_hi - nc_lo, P, a.groupall ? 16 : a.ns);
     if constexpr (P >= 64) {
-        if (wn == 1) return layer3_max<P / 64, 1>(a, A, lda, c2p, row0, b);
+        if (wn == 1) return layer3_max<P / 64, 1>(a, A, lda, c2p, row0, b, nc_lo, nc_hi);
     }
     if constexpr (P >= 32) {
-        if (wn == 2) return layer3_max<P / 32, 2>(a, A, lda, c2p, row0, b);
+        if (wn == 2) return layer3_max<P / 32, 2>(a, A, lda, c2p, row0, b, nc_lo, nc_hi);
     }
-    layer3_max<P / 16, 4>(a, A, lda, c2p, row0, b);
+    layer3_max<P / 16, 4>(a, A, lda, c2p, row0, b, nc_lo, nc_hi);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -11,9 +11,11 @@ constexpr int HID = 256, HEADS = 768, POSE = 9;
 //   16-row tile, R = 3200: 8 waves (two per SIMD) 24.3 us vs 24.3 us with 4 - the tile is bound by the weight stream and its
 //                          phases are barrier-locked, a second wave per SIMD has nothing different to overlap with;
 //   32-row tile, R = 6400: 8 waves 39.2 us vs 40.9 us with 4 - MFMA-bound, the second wave fills epilogue / barrier bubbles.
+//   48-row tile (round 6, the RK45 driver's shared-chunk plan): 4 waves, so that the workgroup can also run a 16-row tile (4 waves) between
+//                          its own passes - one wave per SIMD, 12 accumulator fragments per wave.
 template <int P>
 struct TrunkCfg {
-    static constexpr int NW = (P <= 16) ? 4 : 8;
+    static constexpr int NW = (P <= 16 || P == 48) ? 4 : 8;
     static constexpr int NV = 16 / NW;   // 16-channel chunks of a 256-wide layer per wave
     static constexpr int NT = 64 * NW;   // threads per workgroup
 };
@@ -32,9 +34,9 @@ struct TrunkCfg {
 // 3 % FASTER on its own (77.3 -> 75.0 us at 16 000 rows: 37 KB less LDS traffic per head epilogue).  KEEP (the backward pass of
 // gp_score_div reads both hidden activations) keeps H1 and H2 apart.
 // clouds whose (cvec + tvec) rows a tile stages in LDS: a tile whose rows span more reads them from global memory in the head epilogue
-// (the slow path).  16 / 32 rows: two (k >= 31 candidates per cloud guarantees it for 32 rows); 64 rows: three (k >= 32).
+// (the slow path).  16 / 32 rows: two (k >= 31 candidates per cloud guarantees it for 32 rows); 48 / 64 rows: three (k >= 32).
 template <int P>
-constexpr int trunk_staged_clouds() { return P >= 64 ? 3 : 2; }
+constexpr int trunk_staged_clouds() { return P >= 48 ? 3 : 2; }
 
 template <int P, bool KEEP = false>
 struct TrunkLds {

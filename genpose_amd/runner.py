@@ -202,8 +202,8 @@ class _FrameGraphs:
         pose = pred.to(torch.float32, copy=True)
         pose[:, :, 6:] -= centre.unsqueeze(1)  # posenet_agent.py:516: translations relative to the cloud centre
         energy = self.enet.pose_score_net.evaluate(cvec_e, K, pose.reshape(n * K, 9), self.tvec_e, self.sigma_e, "energy").reshape(n, K, 2)
-        r = reward.rank_aggregate(pred, energy, selected_num=self.sel)
-        return energy, rotation.pose9_to_RT(r["sorted_poses"]), rotation.quat_trans_to_RT(r["avg_pose"])
+        r = reward.rank_aggregate(pred, energy, selected_num=self.sel, with_rt=True)  # ranking, aggregation and both 4x4 forms: one launch
+        return energy, r["sorted_RTs"], r["avg_RT"]
 
     def rank(self, pred, centre, cvec_e):
         """pred [n,K,9] f64 -> (energy [n,K,2], sorted_RTs [n,K,4,4], average_sRT [n,4,4])"""
@@ -296,9 +296,8 @@ class TrackingRunner:
         else:
             pred = self.score_agent.pred_func(data=sample, repeat_num=K, save_path=None, init_x=init_x.float(), T0=self.T0)
             energy = self.energy_agent.get_energy(data=sample, pose_samples=pred, T=1e-5)
-            r = reward.rank_aggregate(pred, energy, selected_num=sel)
-            average_sRT = rotation.quat_trans_to_RT(r["avg_pose"])
-            sorted_RTs = rotation.pose9_to_RT(r["sorted_poses"])
+            r = reward.rank_aggregate(pred, energy, selected_num=sel, with_rt=True)
+            average_sRT, sorted_RTs = r["avg_RT"], r["sorted_RTs"]
         self.buffer = {"model_name": list(model_names), "pred_sRT": average_sRT}
         # (the caller gets its own copy of the aggregated poses: the buffer's tensor is the next frame's warm start)
         return {"init_x": init_x, "pred_pose": pred, "energy": energy, "sorted_RTs": sorted_RTs, "average_sRT": average_sRT.clone()}
@@ -399,9 +398,8 @@ class MultiSequenceTracker:
         # ---- energy model + ranking + aggregation for all clouds at once (row / cloud local)
         energy = self.energy_agent.get_energy(data=shared, pose_samples=pred, T=1e-5)
         sel = max(1, int(self.ratio * K))
-        r = reward.rank_aggregate(pred, energy, selected_num=sel)
-        average_sRT = rotation.quat_trans_to_RT(r["avg_pose"])
-        sorted_RTs = rotation.pose9_to_RT(r["sorted_poses"])
+        r = reward.rank_aggregate(pred, energy, selected_num=sel, with_rt=True)
+        average_sRT, sorted_RTs = r["avg_RT"], r["sorted_RTs"]
         lo = 0
         for_caller = average_sRT.clone()  # one small device-side copy, no synchronisation
         for q, i in enumerate(live):

@@ -204,6 +204,7 @@ class ODESampler:
         self.model = self.MODELS[model]
         self.ncomp = 10 if self.model == 2 else 9
         self.ragged = group_clouds is not None
+        self.shared = False
         if self.ragged and self.model != 0:
             raise NotImplementedError("ragged groups integrate the score network's ODE only")
         self.dev = torch.device(device)
@@ -231,13 +232,21 @@ class ODESampler:
         R = self.R = B * K
         if not self.ragged:
             # forward + backward right-hand sides (energy model, likelihood): 16-row tiles or, for large launches, the 128-row chain form
-            self.plan = int(tile) if tile else _lib.lib().gp_rk45_plan_rows(self.model, groups, B // groups, K)
-            # plan = rows per workgroup (| GP_PLAN_HEADSPLIT: three workgroups per 16-row tile, one head each - the latency regime)
-            self.tile, self.hsplit = self.plan & ~_lib.PLAN_HEADSPLIT, (3 if self.plan & _lib.PLAN_HEADSPLIT else 1)
-            if (self.hsplit == 3 and (self.tile != 16 or self.model != 0)) or self.tile not in (16, 32, 64, 128) or (self.model != 0 and self.tile in (32, 64)) or (groups > 1 and (R // groups) % self.tile):
+            # (a sharded batch's controller runs on all-reduced per-group sums between the stage launches and the decision: not the shared-chunk plan)
+            pick = _lib.lib().gp_rk45_plan_rows if coupling_group is None else _lib.lib().gp_rk45_plan_rows_unshared
+            self.plan = int(tile) if tile else pick(self.model, groups, B // groups, K)
+            # plan = rows per workgroup | GP_PLAN_HEADSPLIT (three workgroups per 16-row tile, one head each - the latency regime)
+            #                           | GP_PLAN_SHARED (one workgroup per CU, the left-over 16-row chunks shared across the stages of an attempt)
+            self.tile, self.hsplit = self.plan & ~_lib.PLAN_FLAGS, (3 if self.plan & _lib.PLAN_HEADSPLIT else 1)
+            self.shared = bool(self.plan & _lib.PLAN_SHARED)
+            if ((self.hsplit == 3 and (self.tile != 16 or self.model != 0)) or self.tile not in (16, 32, 48, 64, 128) or (self.tile == 48 and not self.shared)
+                    or (self.model != 0 and self.tile in (32, 48, 64)) or (groups > 1 and (R // groups) % self.tile)):
                 raise ValueError(f"{B // groups} clouds x {K} candidates per batch do not split into workgroups of plan {tile or 'auto'}; "
                                  "run the batches separately")
-            self.nblocks = groups * ((R // groups + self.tile - 1) // self.tile)
+            npart = _lib.lib().gp_rk45_partials_count(self.model, self.plan, groups, B // groups, K)
+            if npart <= 0:
+                raise ValueError(f"plan {self.plan:#x} does not serve {groups} x {B // groups} clouds x {K} candidates")
+            self.nblocks = npart // (3 * self.hsplit)
         if self.ragged:
             self.set_groups(group_clouds)
         self.layout, nbytes = _state_layout()
@@ -395,6 +404,9 @@ class ODESampler:
                 break
             if n_done >= max_attempts:
                 raise RuntimeError("ODE sampler: attempt budget exhausted")
+        if any(s_["status"] == -2 for s_ in sts):
+            raise RuntimeError("ODE sampler: a stage of the shared-chunk plan never saw its predecessor's state (bounded wait ran out); "
+                               "force a whole-tile plan with ODESampler(..., tile=64)")
         if any(s_["status"] < 0 for s_ in sts):
             raise RuntimeError("ODE sampler: required step size is less than spacing between numbers (scipy TOO_SMALL_STEP)")
         self.group_stats = sts

@@ -372,11 +372,24 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
  * regime's head-split plan (score model): THREE workgroups per 16-row tile, each recomputing pose_encoder and evaluating one head
  * (scorenet.py:178-222: the three fusion tails are independent given the pose features) - half the weight stream and half the MFMA issue
  * per workgroup, 3x the CUs; every stage of an attempt is then a launch of its own (a stage reads all nine components of the previous
- * one); picked by gp_rk45_plan_rows() while tiles x 3 <= CUs (gp_plan_headsplit_pays).  0 = gp_rk45_plan_rows() picks.
- * partials [3][ngroups * ceil(rows_per_group / rows per workgroup) * (3 under the head-split plan)]. */
+ * one); recommended by gp_rk45_plan_rows() while tiles x 3 <= CUs (gp_plan_headsplit_pays).  0 = a whole-tile plan is picked.
+ * partials: gp_rk45_partials_count() doubles ([3][ngroups * ceil(rows_per_group / rows per workgroup) * (3 under the head-split plan)]). */
 #define GP_PLAN_HEADSPLIT 0x100
+/* 16 | GP_PLAN_SHARED or 48 | GP_PLAN_SHARED (round 6; score model, one group; picked by gp_rk45_plan_rows() when it applies): the SHARED-CHUNK plan for
+ * launches whose 16-row chunks do not divide over the CUs - T chunks on C CUs with T / C = 1 or 3 and 6 (T mod C) <= C, e.g. the 12 800 rows
+ * of scripts/eval_single.sh's batches (800 chunks on 256 CUs).  An attempt is ONE launch of C workgroups: each owns T / C whole chunks for
+ * all six stages, and the 6 x (T mod C) (chunk, stage) units of the left-over chunks are dealt out one per workgroup, so the busiest CU
+ * evaluates 6 x (T / C) + 1 chunk-stages per attempt instead of 6 x (T / C + 1) (csrc/rk45.hip: rk45_attempt_shared_kernel).  The other
+ * phases run on the whole-tile plan.  Results: the per-row arithmetic of every other plan; the error norm's partial sums in another order. */
+#define GP_PLAN_SHARED 0x200
 int gp_plan_headsplit_pays(int ntiles16); /* 1 while three workgroups per 16-row tile still get a CU each */
+/* The plan the driver recommends for a launch (may carry GP_PLAN_HEADSPLIT / GP_PLAN_SHARED) and the number of doubles `partials` must hold
+ * under a plan (plan = 0: what gp_rk45_phase_model resolves 0 to - always a WHOLE-tile plan, so that a buffer of 3 x ceil(rows / 16) doubles
+ * per group, the size the entry points without a plan argument document, stays sufficient; the head-split and shared-chunk plans are taken
+ * only when passed explicitly - ABI note in INTEGRATION.md section 3). */
 int gp_rk45_plan_rows(int model, int ngroups, int nclouds_per_group, int k);
+int gp_rk45_plan_rows_unshared(int model, int ngroups, int nclouds_per_group, int k); /* the same without GP_PLAN_SHARED (ext_sums callers) */
+int gp_rk45_partials_count(int model, int plan, int ngroups, int nclouds_per_group, int k);
 int gp_rk45_phase_model(int model, int plan, const float *probe, int phase, int ngroups, int nclouds_per_group, int k, const gp_scorenet *net, const float *cvec,
                         float *tvec, const float *centre, void *state, double *y, double *ynew, double *K, double *partials, double *traj,
                         int traj_cap, double t0, double t_bound, double rtol, double atol, double denoise_scale, int do_denoise, int nstates,
@@ -399,6 +412,11 @@ int gp_rk45_set_dense_grouped(int ngroups, void *state, const double *t_eval_dev
  * order [b,k,2] i32 (stable descending), avg_pose [b,7] f32 (w,x,y,z,tx,ty,tz) over the top `sel` candidates. */
 int gp_rank_aggregate(int b, int k, int sel, int is_f64, const void *poses, const float *energy, void *sorted_poses,
                       float *sorted_energy, int32_t *order, float *avg_pose, gp_stream_t s);
+/* The same launch with the 4x4 forms the runners hand on written by it as well (either may be NULL): sorted_rt [b,k,4,4] f64 =
+ * gp_pose9_to_rt(sorted_poses), avg_rt [b,4,4] f32 = gp_quat_trans_to_rt(avg_pose) - bit for bit; the ranking step of a tracking frame
+ * (evaluation_tracking.py:316-330: energies -> sort -> average) is then one launch behind the energy evaluation. */
+int gp_rank_aggregate_rt(int b, int k, int sel, int is_f64, const void *poses, const float *energy, void *sorted_poses,
+                         float *sorted_energy, int32_t *order, float *avg_pose, double *sorted_rt, float *avg_rt, gp_stream_t s);
 
 /* The 4x4 homogeneous matrices the runners hand on (evaluation_single.py:325-332, evaluation_tracking.py:60-77), one launch each instead of
  * ~15 tensor operations: poses [n][9] (f32 or f64: is_f64) -> out [n][4][4] f64 (Gram-Schmidt of the two rotation columns in f64, as

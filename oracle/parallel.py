@@ -34,13 +34,16 @@ def _init(threads):
     os.environ["OMP_NUM_THREADS"] = str(threads)
 
 
-def _encode_slice(mode, seed, arith, pts):
+def _encode_slice(mode, seed, arith, pts, ckpt=None):
     import torch
     from . import genpose_oracle as go
     from . import pn2_oracle as ops
-    key = (mode, seed)
+    key = (mode, seed, ckpt)
     if key not in _WORKER:
-        _WORKER[key] = go.make_state_dict(seed, mode)
+        if ckpt is None:
+            _WORKER[key] = go.make_state_dict(seed, mode)
+        else:  # a reference-layout checkpoint file (trained weights): loaded once per worker
+            _WORKER[key] = {k: v.float() for k, v in torch.load(ckpt, map_location="cpu")["model_state_dict"].items()}
     with ops.use_arith(arith):
         return go.encoder_forward(_WORKER[key], torch.from_numpy(pts)).numpy()
 
@@ -62,19 +65,20 @@ def shutdown():
         _pool = None
 
 
-def encoder_features(mode, pts, seed=0, arith=None, slice_clouds=16):
-    """go.encoder_forward(go.make_state_dict(seed, mode), pts) for pts [B,1024,3] (numpy or CPU tensor) -> numpy [B,1024]."""
+def encoder_features(mode, pts, seed=0, arith=None, slice_clouds=16, ckpt=None):
+    """go.encoder_forward(go.make_state_dict(seed, mode), pts) for pts [B,1024,3] (numpy or CPU tensor) -> numpy [B,1024].
+    ckpt: path of a reference-layout checkpoint whose 'model_state_dict' replaces the seeded weights (`mode` / `seed` then only label the cache)."""
     from . import pn2_oracle as ops
     arith = arith or ops.current_arith()
     pts = np.ascontiguousarray(pts.numpy() if hasattr(pts, "numpy") else pts, dtype=np.float32)
-    keys = [(mode, seed, arith, hashlib.sha1(pts[i].tobytes()).hexdigest()) for i in range(pts.shape[0])]
+    keys = [(mode, seed, ckpt, arith, hashlib.sha1(pts[i].tobytes()).hexdigest()) for i in range(pts.shape[0])]
     missing = [i for i, k in enumerate(keys) if k not in _cache]
     if missing:
         chunks = [missing[s:s + slice_clouds] for s in range(0, len(missing), slice_clouds)]
         if len(chunks) == 1 and _pool is None:  # a handful of clouds: not worth starting workers
-            outs = [_encode_slice(mode, seed, arith, pts[chunks[0]])]
+            outs = [_encode_slice(mode, seed, arith, pts[chunks[0]], ckpt)]
         else:
-            futs = [pool().submit(_encode_slice, mode, seed, arith, pts[c]) for c in chunks]
+            futs = [pool().submit(_encode_slice, mode, seed, arith, pts[c], ckpt) for c in chunks]
             outs = [f.result() for f in futs]
         for c, o in zip(chunks, outs):
             for i, row in zip(c, o):

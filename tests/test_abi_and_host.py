@@ -336,18 +336,47 @@ def test_bench_spawns_the_documented_launch_line(monkeypatch):
     import bench
     seen = {}
 
-    def fake_call(cmd, env=None):
-        seen["cmd"], seen["env"] = cmd, env
-        return 0
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(seen.get("lines", ['{"metric": "x", "value": 1.0}\n']))
 
-    monkeypatch.setattr(subprocess, "call", fake_call)
+        def wait(self):
+            return seen.get("rc", 0)
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
     monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
-    assert bench.self_launch(argparse.Namespace(gpus=8)) == 0
+    assert bench.self_launch(argparse.Namespace(gpus=8, steps=20, warmup=5)) == 0
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["GP_BENCH_LAUNCH"] == "self" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_prints_a_line_when_the_launcher_dies_without_one(monkeypatch, capsys):
+    """A launcher that ends without rank 0's JSON line (a crash before Python starts, an OOM kill) still yields ONE parseable line with an
+    "error" field - the driver's multi-GPU run must come back diagnosable, not empty."""
+    import argparse
+    import json
+    import subprocess
+    import sys as _sys
+    import bench
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            self.stdout = iter(["some launcher chatter\n"])
+
+        def wait(self):
+            return 9
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4"])
+    assert bench.self_launch(argparse.Namespace(gpus=4, steps=20, warmup=3)) == 9
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == 4 and "exited with code 9" in line["error"]
 
 
 def test_shape_cache_evicts_least_recently_used_and_skips_pins():

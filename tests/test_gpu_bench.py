@@ -129,3 +129,41 @@ def test_one_rank_on_rccl_costs_nothing():
     ratio = rccl["value"] / plain["value"]
     print(f"one rank on RCCL: {rccl['value']:.0f} poses/s against {plain['value']:.0f} plain ({100 * (ratio - 1):+.2f} %)")
     assert ratio > 0.97, (rccl["value"], plain["value"])
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_two_and_four_ranks_on_one_device(n):
+    """The N = 2 and N = 4 points of the driver's scaling curve through the same rehearsal as N = 8."""
+    line = _run(["--gpus", str(n)], {"GP_BENCH_ONE_DEVICE": "1"})
+    assert REQUIRED <= set(line) and line["n_gpus"] == n and line["launch"]["world_size_observed"] == n and "error" not in line
+    assert abs(line["value"] - n * 8 * 2 / (line["ms_per_step"] * 2e-3)) <= 0.01 * line["value"]
+
+
+@pytest.mark.parametrize("launcher", ["self", "external"])
+def test_a_rank_that_dies_before_the_rendezvous_still_yields_a_line(launcher):
+    """The driver's SCALE run is the first time RCCL sees more than one rank: whatever fails there must come back as a parseable line with an
+    "error" field, not as a hang into the driver's time limit.  Rehearsal: rank 1 of 2 exits before init_process_group (GP_BENCH_KILL_RANK);
+    rank 0 sits in the rendezvous until the launcher terminates it or the start timeout fires - either way it prints the line.
+    'external' = the driver's own launch line (python -m torch.distributed.run ... bench.py), 'self' = bench.py spawning it."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"GP_BENCH_ONE_DEVICE": "1", "GP_BENCH_KILL_RANK": "1", "GP_BENCH_START_TIMEOUT": "20"})
+    bench = os.path.join(ROOT, "bench.py")
+    if launcher == "self":
+        cmd = [sys.executable, bench, "--gpus", "2"] + SMALL
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29617",
+               bench, "--gpus", "2"] + SMALL
+    import time
+    t0 = time.time()
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert p.returncode != 0
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == 2 and "error" in line and line["launch"]["backend"] == "gloo", line
+    assert line["launch"]["device_count"] >= 1
+    assert took < 120, took  # seconds, not the driver's 1 800 s limit
+    print(f"killed-rank rehearsal ({launcher}): line after {took:.0f} s: {line['error']}")

@@ -90,25 +90,39 @@ def test_ode_golden(golden, case):
     if first_diff is None:
         assert abs(int(stats["nfev"]) - ref_nfev) <= 6  # at most the last, ulp-sized step differs
     same_count = int(stats["nfev"]) == ref_nfev
-    if same_count:
+    # one attempt more or fewer with an identical accept / reject prefix = the last, ulp-sized step to t_bound exists on one side only
+    # (observed on the driver's box for T0 = 1: 417 against 411 evaluations): everything before it is comparable and is compared
+    tail_only = (not same_count) and first_diff is None and abs(int(stats["nfev"]) - ref_nfev) <= 6
+    if same_count or tail_only:
         ref_t = g[f"{case}_eval_t"]
         # same accept/reject sequence, and every attempt starts where the reference's did: first stage evaluation of an
         # attempt sits at t + h/5 (Dormand-Prince c_2).  Step sizes follow err^(-1/5), so fp32-level differences in the
         # score move them by ~1e-3 relative late in the integration; the reference logged f32 times.
-        assert [bool(a) for a in stats["log_acc"]] == _ref_accepts(ref_t)
-        np.testing.assert_allclose(stats["log_t"] + 0.2 * stats["log_h"], ref_t[2:-1:6][: len(stats["log_t"])], rtol=2e-3, atol=2e-5)
+        common = min(len(acc_dev), len(acc_ref))
+        assert acc_dev[:common] == acc_ref[:common] and (tail_only or len(acc_dev) == len(acc_ref))
+        dev_first_stage = (np.asarray(stats["log_t"]) + 0.2 * np.asarray(stats["log_h"]))[:common]
+        np.testing.assert_allclose(dev_first_stage, ref_t[2:-1:6][:common], rtol=2e-3, atol=2e-5)
         if proc is not None:
-            assert list(proc.shape) == list(g[f"{case}_proc_shape"])
-            ode_close(proc[:, :, -3:].cpu().numpy(), g[f"{case}_proc_last3"])
+            extra = proc.shape[2] - int(g[f"{case}_proc_shape"][2])  # accepted states the device has beyond the reference's (0 unless tail_only)
+            assert list(proc.shape[:2]) + [proc.shape[3]] == [int(v) for v in np.asarray(g[f"{case}_proc_shape"])[[0, 1, 3]]] and abs(extra) <= (1 if tail_only else 0)
             ode_close(proc[:, :, :2].cpu().numpy(), g[f"{case}_proc_first2"])
+            last3 = g[f"{case}_proc_last3"]
+            if extra == 0:
+                ode_close(proc[:, :, -3:].cpu().numpy(), last3)
+            elif extra > 0:    # [.., s(n-2), s(n-1), s(n), s(n) again after an ulp-sized step]
+                ode_close(proc[:, :, -3 - extra:-extra].cpu().numpy(), last3)
+            else:              # the reference took the ulp-sized step: its last state repeats the one before
+                ode_close(proc[:, :, -3 - extra:].cpu().numpy(), last3[:, :, :3 + extra])
     # which branch ran is part of the result: the non-chaotic cases must take the reference's evaluation count exactly (and with it
     # the full-trajectory asserts above); only the chaotic T0 = 1 problems may drift late, inside the bounds asserted before
     may_drift = float(g[f"{case}_T0"]) >= 1.0
     assert same_count or may_drift, f"{case}: {stats['nfev']} evaluations against the reference's {ref_nfev} on a non-chaotic problem"
-    if not same_count:
+    if not (same_count or tail_only):
         import warnings
         warnings.warn(f"test_ode_golden[{case}]: schedule drifted late (nfev {stats['nfev']} vs {ref_nfev}, first flip at attempt {first_diff}); "
                       "end pose, leading attempts and evaluation-count bounds were checked, the full-trajectory asserts were not")
+    elif tail_only:
+        print(f"test_ode_golden[{case}]: one final attempt of difference (nfev {stats['nfev']} vs {ref_nfev}); trajectory asserts ran over the {common} common attempts")
 
 
 def test_pc_agent_golden(golden):
@@ -161,6 +175,25 @@ def test_rank_ties_and_sizes():
         np.testing.assert_allclose(r["avg_pose"].cpu().numpy()[:, 4:], qt.numpy()[:, 4:], atol=1e-5)
         dot = np.abs(np.sum(r["avg_pose"].cpu().numpy()[:, :4] * qt.numpy()[:, :4], axis=1))
         assert np.all(dot > 1 - 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_rank_aggregate_one_launch_with_the_matrices(dtype):
+    """gp_rank_aggregate_rt (ranking + aggregation + both 4x4 forms in one launch: what a tracking frame's ranking step runs) gives the
+    bits of gp_rank_aggregate followed by gp_pose9_to_rt and gp_quat_trans_to_rt."""
+    from genpose_amd import reward, rotation
+    gen = torch.Generator().manual_seed(3)
+    for B, K, sel in [(1, 1, 1), (5, 50, 30), (3, 130, 7), (64, 50, 30)]:
+        poses = torch.randn(B, K, 9, generator=gen).to(dtype).cuda()
+        energy = torch.randn(B, K, 2, generator=gen).cuda()
+        a = reward.rank_aggregate(poses, energy, selected_num=sel)
+        b = reward.rank_aggregate(poses, energy, selected_num=sel, with_rt=True)
+        for k in ("sorted_poses", "sorted_energy", "order", "avg_pose"):
+            assert torch.equal(a[k], b[k]), k
+        assert torch.equal(b["sorted_RTs"], rotation.pose9_to_RT(a["sorted_poses"]))
+        assert torch.equal(b["avg_RT"], rotation.quat_trans_to_RT(a["avg_pose"]))
+        c = reward.rank_aggregate(poses, energy, with_rt=True)  # ranking only
+        assert c["avg_RT"] is None and torch.equal(c["sorted_RTs"], b["sorted_RTs"])
 
 
 def _ref_accepts(ref_t):

@@ -1,0 +1,278 @@
+"""GPU parity OUTSIDE the seed-0 random-weight regime: the score model and the energy model trained on synthetic posed clouds
+(scratch/train_synth.py: the reference-pinned training step of genpose_amd/training.py looped on the device for a bounded budget; the
+checkpoints under tests/golden/trained/ are reference-layout files, what PoseNet.load_ckpt reads) - trained BatchNorm statistics,
+trained output layers, a sampler that pulls candidates into modes instead of walking at random.
+
+  checkpoints      reference key schema, loaded through PoseNet.load_ckpt AND into the oracle (the same state dict)
+  configs[1] batch 64 held-out clouds x 50 candidates x 100 PC steps against the oracle - the tolerance of the random-weight test
+  eval_single      256 held-out clouds, ODE from T0 = 0.55 over 12 800 coupled rows: evaluation count, accept / reject schedule, poses of every
+                   row, energies, exact ranking permutation, aggregation - the tolerances of the random-weight tests
+  accuracy proxy   5deg2cm / 5deg5cm / 10deg2cm / 10deg5cm of evaluation.compute_mAP on held-out synthetic instances with known poses: HIP path
+                   against the oracle with identical draws (north star: within 0.5 pt), HIP path with its own draws, opt-in split-bf16 forms
+Every tolerance is imported from the random-weight tests: if one had to move for trained weights, that would be the finding.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import genpose_oracle as go
+from oracle import parallel as opar
+
+from test_gpu_fullsize import ENC_ATOL, ENC_RTOL, _assert_pc100_close, _check_pose_properties, _host_threads
+from test_gpu_sampler import ODE_ROT_ATOL, ODE_RTOL
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CKPT = {m: os.path.join(HERE, "golden", "trained", f"ckpt_{m}.pth") for m in ("score", "energy")}
+HELD_OUT = 1_000_000  # synth.make_posed_cloud indices the training run never saw (it used 0 .. 49 151)
+K, T0, RATIO = 50, 0.55, 0.6
+REPORT = os.environ.get("GP_PROXY_REPORT")  # path: write the accuracy-proxy table there (profiles/r6_accuracy_proxy.txt)
+N_PROXY = int(os.environ.get("GP_PROXY_INSTANCES", "256"))
+
+
+def _sd(mode):
+    assert os.path.exists(CKPT[mode]), f"{CKPT[mode]} is missing: the trained checkpoints are committed fixtures (scratch/train_synth.py makes them)"
+    return {k: v.float() for k, v in torch.load(CKPT[mode], map_location="cpu")["model_state_dict"].items()}
+
+
+def _agent(mode, sampler="ode", steps=None, **cfg):
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    a = PoseNet(get_config(posenet_mode=mode, sampler_mode=[sampler], sampling_steps=steps, **cfg))
+    a.load_ckpt(model_dir=CKPT[mode], model_path=True, load_model_only=True)
+    return a
+
+
+def _posed(n, start=HELD_OUT):
+    from genpose_amd import synth
+    return synth.posed_batch(range(start, start + n))
+
+
+def test_checkpoints_are_reference_layout_and_trained():
+    sd, sde = _sd("score"), _sd("energy")
+    ref_keys = set(go.make_state_dict(0, "score"))
+    assert set(sd) == ref_keys and set(sde) == ref_keys
+    for d in (sd, sde):
+        # zero-initialised output layers (scorenet.py:156-170) have moved, BatchNorm statistics are no longer (0, 1), nothing is NaN
+        assert all(torch.isfinite(v.float()).all() for v in d.values())
+        assert float(d["pose_score_net.fusion_tail_trans.2.weight"].abs().max()) > 1e-3
+        rv = d["pts_encoder.SA_modules.2.mlps.0.layer1.bn.bn.running_var"]
+        assert float((rv - 1).abs().max()) > 0.05 and int(d["pts_encoder.SA_modules.0.mlps.0.layer0.bn.bn.num_batches_tracked"]) > 100
+    a = _agent("score")
+    w = a.net.pose_score_net  # the agent holds the file's weights (spot check through the oracle below; here: it loaded at all)
+    assert w is not None
+
+
+def test_config1_batch_pc100_trained():
+    """BASELINE configs[1] geometry (64 clouds x 50 candidates x 100 PC steps, injected draws) on the TRAINED score model: agent against
+    the CPU oracle holding the same state dict."""
+    B, n = 64, 100
+    d = _posed(B, HELD_OUT + 5000)
+    pts = torch.from_numpy(d["pts"])
+    gen = torch.Generator().manual_seed(31)
+    prior = torch.randn(B * K, 9, generator=gen)
+    z1, z2 = torch.randn(n, B * K, 9, generator=gen), torch.randn(n, B * K, 9, generator=gen)
+    a = _agent("score", "pc", n)
+    a.net.prior_fn = lambda shape, T=1.0: prior * float(go.ve_sigma(1.0))
+    dev = pts.cuda()
+    data = {"pts": dev, "pts_center": dev.mean(dim=1)}
+    got = a.pred_func(data, K, save_path=None, noise=(z1.cuda(), z2.cuda()))
+    torch.cuda.synchronize()
+    _check_pose_properties(got)
+    feat = opar.encoder_features("score", pts, ckpt=CKPT["score"])
+    np.testing.assert_allclose(data["pts_feat"].cpu().numpy(), feat, rtol=ENC_RTOL, atol=ENC_ATOL * max(1.0, float(np.abs(feat).max())))
+    sd = _sd("score")
+    feat_r = torch.from_numpy(feat).repeat_interleave(K, 0)
+    cen_r = pts.mean(dim=1).repeat_interleave(K, 0)
+    with _host_threads():
+        _, ref = go.pc_sampler(lambda x, t: go.score_forward(sd, feat_r, x, t), prior * float(go.ve_sigma(1.0)), cen_r, n, z1, z2)
+    _assert_pc100_close(got.cpu().numpy(), ref.reshape(B, K, 9).numpy(), "trained weights, configs[1] batch (3200 rows x 100 steps) vs oracle")
+
+
+# ---------------------------------------------------------------------------------------------- eval_single shape + accuracy proxy
+def _hip_batch(sa, ea, pts, prior):
+    """One batch exactly as SingleFrameRunner.infer_tensors runs it (runner.py:52-66), with the prior draw injected (None: the agent's own)."""
+    from genpose_amd import reward, rotation
+    from genpose_amd.runner import make_batch_sample
+    if prior is not None:
+        sa.net.prior_fn = lambda shape, T=1.0: prior * float(go.ve_sigma(T))
+    sample = make_batch_sample(pts)
+    pred = sa.pred_func(data=sample, repeat_num=K, save_path=None, T0=T0)
+    energy = ea.get_energy(data=sample, pose_samples=pred, T=1e-5)
+    r = reward.rank_aggregate(pred, energy, ratio=RATIO)
+    out = {"pred": pred, "energy": energy, "order": r["order"], "sorted_poses": r["sorted_poses"], "sorted_energy": r["sorted_energy"],
+           "avg_pose": r["avg_pose"], "feat": sample["pts_feat"], "sorted_RTs": rotation.pose9_to_RT(r["sorted_poses"])}
+    out = {k: v.cpu().clone() for k, v in out.items()}
+    stats = getattr(sa.net, "last_sampler", None)
+    if stats is not None and getattr(stats, "last_stats", None) and "nfev" in stats.last_stats:
+        out["nfev"] = int(stats.last_stats["nfev"])
+        out["log_acc"] = [bool(x) for x in stats.last_stats["log_acc"]]
+    return out
+
+
+def _oracle_batch(pts_cpu, prior):
+    sd, sde = _sd("score"), _sd("energy")
+    B = pts_cpu.shape[0]
+    feat = torch.from_numpy(opar.encoder_features("score", pts_cpu, ckpt=CKPT["score"]))
+    feat_e = torch.from_numpy(opar.encoder_features("energy", pts_cpu, ckpt=CKPT["energy"]))
+    cen = pts_cpu.mean(dim=1)
+    cen_r = cen.repeat_interleave(K, 0)
+    log = []
+    with _host_threads():
+        feat_r = feat.repeat_interleave(K, 0)
+        _, x, nfev = go.ode_sampler(lambda xx, t: go.score_forward(sd, feat_r, xx, t), prior * go.ve_sigma(T0), cen_r, T0, log=log)
+        pose = x.clone().float()
+        pose[:, -3:] -= cen_r
+        energy = go.energy_forward(sde, feat_e.repeat_interleave(K, 0), pose, torch.ones(B * K, 1) * 1e-5).reshape(B, K, 2)
+    pred = x.reshape(B, K, 9)
+    sorted_poses, sorted_energy = go.sort_poses_by_energy(pred, energy)
+    sorted_RT = go.pose9_to_RT(sorted_poses)
+    avg_RT, qt = go.aggregate_sorted(sorted_RT, ratio=RATIO)
+    return {"pred": pred, "energy": energy, "sorted_poses": sorted_poses, "sorted_energy": sorted_energy, "sorted_RTs": torch.from_numpy(sorted_RT),
+            "avg_qt": qt, "feat": feat, "nfev": nfev, "log_acc": [bool(e["accepted"]) for e in log]}
+
+
+def _map_results(d, sorted_RTs, sorted_energy):
+    """One 'image' per instance in the container layout evaluation.compute_mAP consumes (DetectionResults.results()): the detection is
+    given (same class, same box), the pose hypotheses ranked by energy as pred_energy_batch stores them."""
+    res = []
+    box = np.array([[10, 10, 110, 110]], dtype=np.int32)
+    for i in range(sorted_RTs.shape[0]):
+        gt = np.eye(4)
+        gt[:3, :3], gt[:3, 3] = d["R"][i], d["t"][i]
+        cls = np.array([int(d["cat"][i]) + 1], dtype=np.int32)
+        res.append({"gt_class_ids": cls, "gt_bboxes": box, "gt_RTs": gt[None], "gt_scales": np.ones((1, 3)), "gt_handle_visibility": np.ones(1, dtype=np.int32),
+                    "pred_class_ids": cls, "pred_bboxes": box, "pred_scores": np.ones(1), "pred_RTs": np.eye(4)[None], "pred_scales": np.ones((1, 3)),
+                    "multi_hypothesis_pred_RTs": np.asarray(sorted_RTs[i], dtype=np.float64)[None], "energy": np.asarray(sorted_energy[i], dtype=np.float64)[None]})
+    return res
+
+
+def _proxy(d, sorted_RTs, sorted_energy):
+    from genpose_amd import evaluation
+    deg, sh, iou = [5, 10], [2, 5, 10], [0.1]
+    iou_aps, pose_aps, _, _ = evaluation.compute_mAP(_map_results(d, sorted_RTs, sorted_energy), None, deg, sh, iou, iou_pose_thres=0.1,
+                                                     use_matches_for_pose=True, repeat_num=K, pooling_mode="average", ratio=RATIO, ranker="energy_ranker")
+    return evaluation.summary(iou_aps, pose_aps, iou, deg + [360], sh + [100])
+
+
+@pytest.fixture(scope="module")
+def eval_single():
+    """N_PROXY held-out instances in batches of 256 (scripts/eval_single.sh): HIP agents and oracle with the SAME prior draws."""
+    nb = max(1, N_PROXY // 256)
+    d = _posed(256 * nb)
+    sa, ea = _agent("score"), _agent("energy")
+    gen = torch.Generator().manual_seed(2026)
+    hip, ora, priors = [], [], []
+    for b in range(nb):
+        pts = torch.from_numpy(d["pts"][256 * b:256 * (b + 1)])
+        prior = torch.randn(256 * K, 9, generator=gen)
+        priors.append(prior)
+        hip.append(_hip_batch(sa, ea, pts.cuda(), prior))
+        ora.append(_oracle_batch(pts, prior))
+    return {"d": d, "hip": hip, "ora": ora, "priors": priors, "agents": (sa, ea)}
+
+
+def test_eval_single_shape_trained(eval_single):
+    """scripts/eval_single.sh's shape (256 clouds, ODE from T0 = 0.55, K = 50, energy ranking, top-60 % aggregation) on trained weights,
+    batch 0 against the oracle."""
+    h, o = eval_single["hip"][0], eval_single["ora"][0]
+    B = 256
+    np.testing.assert_allclose(h["feat"].numpy(), o["feat"].numpy(), rtol=ENC_RTOL, atol=ENC_ATOL * max(1.0, float(o["feat"].abs().max())))
+    # the adaptive solve: same evaluation count (one attempt of slack), same accept / reject decisions over the common attempts
+    assert abs(h["nfev"] - o["nfev"]) <= 6, (h["nfev"], o["nfev"])
+    common = min(len(h["log_acc"]), len(o["log_acc"]))
+    flips = [i for i in range(common) if h["log_acc"][i] != o["log_acc"][i]]
+    print(f"trained ODE T0={T0}: nfev {h['nfev']} (oracle {o['nfev']}), attempts {len(h['log_acc'])} / {len(o['log_acc'])}, rejected {o['log_acc'].count(False)}, flips {flips}")
+    assert not flips
+    got, ref = h["pred"].numpy().reshape(B * K, 9), o["pred"].numpy().reshape(B * K, 9)
+    assert h["pred"].dtype == torch.float64
+    _check_pose_properties(h["pred"].float())
+    np.testing.assert_allclose(got[:, :6], ref[:, :6], rtol=0, atol=ODE_ROT_ATOL, err_msg="rotation block, 12800 rows")
+    np.testing.assert_allclose(got[:, 6:], ref[:, 6:], rtol=0, atol=ODE_RTOL * max(1.0, float(np.abs(ref[:, 6:]).max())), err_msg="translations")
+    # energies of the DEVICE's candidates through the oracle's energy network (the poses agree to 2e-3; compare like with like)
+    sde = _sd("energy")
+    sl = slice(32, 64)
+    d = eval_single["d"]
+    pts = torch.from_numpy(d["pts"][:256])
+    cen = pts.mean(dim=1)
+    feat_e = torch.from_numpy(opar.encoder_features("energy", pts, ckpt=CKPT["energy"]))[sl]
+    pose = h["pred"][sl].reshape(-1, 9).float().clone()
+    pose[:, -3:] -= cen[sl].repeat_interleave(K, 0)
+    ref_e = go.energy_forward(sde, feat_e.repeat_interleave(K, 0), pose, torch.ones(pose.shape[0], 1) * 1e-5).reshape(-1, K, 2).numpy()
+    np.testing.assert_allclose(h["energy"][sl].numpy(), ref_e, rtol=5e-4, atol=5e-4 * np.abs(ref_e).max())
+    # ranking: the exact stable descending permutation of the device's energies on all 256 clouds; sorted tensors consistent with it
+    e_cpu, order = h["energy"], h["order"].long()
+    for c in range(2):
+        srt = torch.sort(e_cpu[:, :, c], dim=1, descending=True, stable=True)
+        assert torch.equal(order[:, :, c], srt.indices)
+        assert torch.equal(h["sorted_energy"][:, :, c], srt.values)
+    # how well separated are trained energies?  (random weights: gaps of 1e-3 relative; a trained energy model spreads them)
+    gap = (h["sorted_energy"][:, :-1] - h["sorted_energy"][:, 1:]).abs() / h["sorted_energy"].abs().amax(dim=1, keepdim=True)
+    print(f"trained energies: median relative gap between neighbours in the ranking {float(gap.median()):.2e}, smallest {float(gap.min()):.2e}")
+    # aggregation of the device's ranking through the oracle
+    _, qt = go.aggregate_sorted(go.pose9_to_RT(h["sorted_poses"][sl]), ratio=RATIO)
+    a = h["avg_pose"][sl].numpy()
+    np.testing.assert_allclose(a[:, 4:], qt.numpy()[:, 4:], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(qt.numpy()[:, 4:]).max())))
+    assert np.all(np.abs(np.sum(a[:, :4] * qt.numpy()[:, :4], axis=1)) > 1 - 1e-5)
+
+
+def test_accuracy_proxy_within_half_a_point(eval_single):
+    """north star: '5deg5cm accuracy within +-0.5 pt of reference'.  REAL275 and the shipped checkpoints are unreachable; the proxy is the
+    same metric code (evaluation.compute_mAP, pinned to the reference by G10) on held-out synthetic instances with known poses, HIP path
+    against the oracle on identical draws.  Also reported (not asserted against the oracle): the HIP path with its own draws, and the two
+    opt-in split-bf16 forms."""
+    from genpose_amd import rotation
+    d, nb = eval_single["d"], len(eval_single["hip"])
+    cat = lambda key, runs: np.concatenate([np.asarray(r[key]) for r in runs], 0)
+    rows = []
+    hip = _proxy(d, cat("sorted_RTs", eval_single["hip"]), cat("sorted_energy", eval_single["hip"]))
+    ora = _proxy(d, cat("sorted_RTs", eval_single["ora"]), cat("sorted_energy", eval_single["ora"]))
+    rows.append(("HIP path, fp32, draws shared with the oracle", hip))
+    rows.append(("CPU oracle, the same draws", ora))
+    sa, ea = eval_single["agents"]
+    from genpose_amd.sde import init_sde
+    sa.net.prior_fn = init_sde("ve")[0]  # back to the agent's own generator
+    torch.manual_seed(7)
+    own = [_hip_batch(sa, ea, torch.from_numpy(d["pts"][256 * b:256 * (b + 1)]).cuda(), None) for b in range(nb)]
+    rows.append(("HIP path, fp32, its own draws", _proxy(d, cat("sorted_RTs", own), cat("sorted_energy", own))))
+    # opt-in split-bf16 encoder (both models), ODE sampler, the shared draws
+    sb, eb = _agent("score", encoder_precision="bf16x3"), _agent("energy", encoder_precision="bf16x3")
+    bf = [_hip_batch(sb, eb, torch.from_numpy(d["pts"][256 * b:256 * (b + 1)]).cuda(), eval_single["priors"][b]) for b in range(nb)]
+    rows.append(("HIP path, encoder_precision='bf16x3' (opt-in), shared draws", _proxy(d, cat("sorted_RTs", bf), cat("sorted_energy", bf))))
+    # PC-100 sampler: fp32 and the opt-in split-bf16 PC step, the same injected noise
+    n = 100
+    gen = torch.Generator().manual_seed(99)
+    runs = {"f32": [], "bf16x3": []}
+    for b in range(nb):
+        pts = torch.from_numpy(d["pts"][256 * b:256 * (b + 1)]).cuda()
+        prior = torch.randn(256 * K, 9, generator=gen)
+        z = (torch.randn(n, 256 * K, 9, generator=gen).cuda(), torch.randn(n, 256 * K, 9, generator=gen).cuda())
+        for prec in runs:
+            ag = _agent("score", "pc", n, sampler_precision=prec)
+            ag.net.prior_fn = lambda shape, T=1.0: prior * float(go.ve_sigma(1.0))
+            from genpose_amd import reward
+            from genpose_amd.runner import make_batch_sample
+            sample = make_batch_sample(pts)
+            pred = ag.pred_func(data=sample, repeat_num=K, save_path=None, noise=z)
+            energy = ea.get_energy(data=sample, pose_samples=pred, T=1e-5)
+            r = reward.rank_aggregate(pred, energy, ratio=RATIO)
+            runs[prec].append({"sorted_RTs": rotation.pose9_to_RT(r["sorted_poses"]).cpu(), "sorted_energy": r["sorted_energy"].cpu()})
+    rows.append(("HIP path, PC sampler 100 steps, fp32", _proxy(d, cat("sorted_RTs", runs["f32"]), cat("sorted_energy", runs["f32"]))))
+    rows.append(("HIP path, PC sampler 100 steps, sampler_precision='bf16x3' (opt-in)", _proxy(d, cat("sorted_RTs", runs["bf16x3"]), cat("sorted_energy", runs["bf16x3"]))))
+    keys = ["5deg2cm", "5deg5cm", "10deg2cm", "10deg5cm", "10deg10cm"]
+    lines = [f"accuracy proxy: {256 * nb} held-out synthetic instances (synth.make_posed_cloud {HELD_OUT}..), K = {K}, ODE T0 = {T0} unless stated, "
+             f"top {int(RATIO * 100)} % by energy averaged; evaluation.compute_mAP, mean AP over the six categories, percent",
+             f"{'':72s}" + "".join(f"{k:>11s}" for k in keys)]
+    for name, s in rows:
+        lines.append(f"{name:72s}" + "".join(f"{s[k]:11.2f}" for k in keys))
+    delta = {k: hip[k] - ora[k] for k in keys}
+    lines.append(f"{'HIP - oracle (shared draws)':72s}" + "".join(f"{delta[k]:+11.2f}" for k in keys))
+    print("\n".join(lines))
+    if REPORT:
+        with open(REPORT, "w") as f:
+            f.write("\n".join(lines) + "\n")
+    assert abs(delta["5deg5cm"]) <= 0.5, delta
+    assert all(abs(v) <= 1.0 for v in delta.values()), delta
