@@ -254,12 +254,20 @@ class Pointnet2EncoderHIP:
                 return direct()
             buf = pts[..., 0:3].contiguous().clone()
             B, N = buf.shape[0], buf.shape[1]
+            # the workspace the replay writes into is pinned BEFORE the capture: were it evicted between the first (direct) call and this
+            # one, _workspace() would otherwise allocate it inside torch.cuda.graph - in the graph's private pool - while the cache holds it
+            pinned = [self.pin_workspaces(B, N, 0)]
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self.forward(buf, grouping=grouping) if grouping is not None else self._forward_with_grouping(buf)
-            # `grouping` is kept alive (its id() is part of the key); the workspace the replay writes into is pinned
-            ent = {"graph": g, "buf": buf, "out": out, "grouping": grouping, "pinned": [self.pin_workspaces(B, N, 0)]}
+            try:
+                with torch.cuda.graph(g):
+                    out = self.forward(buf, grouping=grouping) if grouping is not None else self._forward_with_grouping(buf)
+            except BaseException:
+                for ws in pinned:
+                    ws["_pins"] -= 1
+                raise
+            # `grouping` is kept alive (its id() is part of the key)
+            ent = {"graph": g, "buf": buf, "out": out, "grouping": grouping, "pinned": pinned}
             self._pass_graphs[key] = ent
         ent["buf"].copy_(pts[..., 0:3])
         if grouping is None:

@@ -29,6 +29,9 @@ class ShapeCache:
         return len(self._d)
 
     def __setitem__(self, key, value):
+        old = self._d.get(key, self)
+        if old is not self and old is not value and self.on_evict is not None:
+            self.on_evict(key, old)  # an overwritten entry is dropped like an evicted one (its pins go back)
         self._d[key] = value
         self._d.move_to_end(key)
         if len(self._d) > self.capacity:
@@ -48,7 +51,13 @@ class ShapeCache:
         return v
 
     def pop(self, key, default=None):
-        return self._d.pop(key, default)
+        """Removes and returns the entry; on_evict runs for it (whatever it pinned is released), like for every other way out."""
+        if key not in self._d:
+            return default
+        v = self._d.pop(key)
+        if self.on_evict is not None:
+            self.on_evict(key, v)
+        return v
 
     def values(self):
         return self._d.values()
@@ -60,4 +69,7 @@ class ShapeCache:
         return self._d.items()
 
     def clear(self):
+        if self.on_evict is not None:
+            for k, v in list(self._d.items()):
+                self.on_evict(k, v)
         self._d.clear()

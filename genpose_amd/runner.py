@@ -176,15 +176,16 @@ class _FrameGraphs:
             grouping, _, _ = self._score_body(buf)  # warm-up outside capture: workspaces, kernel attributes
             self._energy_body(buf, grouping)
             torch.cuda.synchronize()
+            # the replays write into encoder workspaces that were allocated outside the captures (by the warm-up above): pinned - BEFORE the
+            # captures, so that none of them can be re-allocated inside one - for as long as these graphs live
+            n, N = int(buf.shape[0]), int(buf.shape[1])
+            pinned = [self.snet.pts_encoder.pin_workspaces(n, N, self.SLOT), self.enet.pts_encoder.pin_workspaces(n, N, self.SLOT)]
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 grouping, centre, cvec_s = self._score_body(buf)
             ge = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ge, stream=self.side):
                 cvec_e = self._energy_body(buf, grouping)
-            # the replays write into encoder workspaces that were allocated outside the captures: pinned while these graphs live
-            n, N = int(buf.shape[0]), int(buf.shape[1])
-            pinned = [self.snet.pts_encoder.pin_workspaces(n, N, self.SLOT), self.enet.pts_encoder.pin_workspaces(n, N, self.SLOT)]
             ent = self._a[key] = (ga, ge, buf, (centre, cvec_s, cvec_e), pinned)
         ga, ge, buf, outs, _ = ent
         cur.wait_event(self.ev_e)  # the previous frame's A' (side stream) has finished reading `buf`, which is about to change

@@ -398,6 +398,17 @@ def test_shape_cache_evicts_least_recently_used_and_skips_pins():
     c["f"] = {"pin": True}
     c["g"] = {"pin": True}
     assert all(v.get("pin") for v in c.values())  # nothing evictable is left: the cache exceeds its soft capacity rather than drop a pin
+    # every way OUT of the cache runs on_evict (an entry that pinned workspaces gives them back): pop, overwrite, clear
+    ev2 = []
+    d = ShapeCache(4, on_evict=lambda k, v: ev2.append((k, v["id"])))
+    d["x"], d["y"], d["z"] = {"id": 1}, {"id": 2}, {"id": 3}
+    assert d.pop("x")["id"] == 1 and d.pop("nope", "dflt") == "dflt" and ev2 == [("x", 1)]
+    d["y"] = {"id": 22}                                      # overwrite: the old entry is dropped
+    same = d["z"]
+    d["z"] = same                                            # re-inserting the same object is not a drop
+    assert ev2 == [("x", 1), ("y", 2)]
+    d.clear()
+    assert sorted(ev2[2:]) == [("y", 22), ("z", 3)] and len(d) == 0
     from genpose_amd.config import get_config
     from genpose_amd.posenet_agent import PoseNet
     net = PoseNet(get_config(device="cpu")).net
