@@ -131,9 +131,9 @@ class _StartGuard:
         self.args, self.rank, self.world, self.backend, self.done, self.timer = args, rank, world, None, False, None
 
     def line(self, msg):
-        import torch
+        torch = sys.modules.get("torch")  # (not imported here: this may run on the watcher thread while the main thread is still importing it)
         try:
-            ndev = torch.cuda.device_count()
+            ndev = torch.cuda.device_count() if torch is not None else None
         except Exception:  # noqa: BLE001
             ndev = None
         return json.dumps({"metric": "poses/sec (1024-pt cloud, 50 cand x 100 SDE steps)", "value": None, "unit": "poses/s", "n_gpus": self.args.gpus,
@@ -189,14 +189,17 @@ def main():
     # GP_BENCH_FORCE_LAUNCH=1 (self-test): take the spawn path for one rank too
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("GP_BENCH_FORCE_LAUNCH") == "1"):
         raise SystemExit(self_launch(args))
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     guard = _StartGuard(args, rank, world)
+    if world > 1:
+        guard.watch_sigterm()  # from the first moment on: a peer may die while this rank is still importing torch
+    import torch
     if world != args.gpus:
         guard.fail(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}", code=2)
     if os.environ.get("GP_BENCH_KILL_RANK") == str(rank):  # rehearsal of a rank that dies before the rendezvous (tests/test_gpu_bench.py)
+        time.sleep(float(os.environ.get("GP_BENCH_KILL_AFTER", "3")))
         os._exit(17)
     # GP_BENCH_ONE_DEVICE=1 (self-test on a 1-GPU box): every rank uses cuda:0 and the collectives run on gloo
     one_dev = os.environ.get("GP_BENCH_ONE_DEVICE") == "1"
@@ -215,7 +218,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = guard.backend = "gloo" if one_dev else "nccl"  # "nccl" = RCCL on ROCm
         limit = float(os.environ.get("GP_BENCH_START_TIMEOUT", "180"))
-        guard.watch_sigterm()
+        if world == 1:
+            guard.watch_sigterm()
         guard.arm(limit + 30, f"process group start ({backend}, {world} ranks)")
         try:
             to = datetime.timedelta(seconds=limit)
@@ -583,7 +587,7 @@ def pc_roofline(torch, smp, rows, n, flop_row=FLOP_SCORE_ROW):
                 "flops_per_launch": flops_per_launch}
     # HBM-side bytes per launch come from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in separate
     # rocprofv3 runs, gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); only valid for the profiled shape
-    for name in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tpath):
             continue

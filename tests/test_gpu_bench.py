@@ -163,7 +163,9 @@ def test_a_rank_that_dies_before_the_rendezvous_still_yields_a_line(launcher):
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
     line = json.loads(lines[0])
-    assert line["value"] is None and line["n_gpus"] == 2 and "error" in line and line["launch"]["backend"] == "gloo", line
-    assert line["launch"]["device_count"] >= 1
+    assert line["value"] is None and line["n_gpus"] == 2 and "error" in line, line
+    # rank 0's own line (not the self-launcher's fallback for a launcher that died silently): it names the backend it was bringing up (None
+    # if the launcher's SIGTERM arrived before the process group was started) and what torch sees of the box
+    assert line["launch"]["rank"] == 0 and line["launch"]["backend"] in ("gloo", None) and line["launch"]["world_size_env"] == 2, line
     assert took < 120, took  # seconds, not the driver's 1 800 s limit
     print(f"killed-rank rehearsal ({launcher}): line after {took:.0f} s: {line['error']}")

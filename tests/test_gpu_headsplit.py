@@ -41,7 +41,8 @@ def test_plan_rule():
     assert lib.gp_rk45_plan_rows(0, 1, 1, 10) == 16 | HS      # BASELINE configs[0]: one tile
     assert lib.gp_rk45_plan_rows(0, 1, 27, 50) == 16 | HS     # 1350 rows = 85 tiles
     assert lib.gp_rk45_plan_rows(0, 1, 28, 50) == 16          # 88 tiles: plain tiles again
-    assert lib.gp_rk45_plan_rows(0, 1, 256, 50) in (32, 64)
+    assert lib.gp_rk45_plan_rows(0, 1, 256, 50) in (32, 64, 48 | 0x200)  # (256 CUs: the shared-chunk plan, tests/test_gpu_shared_plan.py)
+    assert lib.gp_rk45_plan_rows_unshared(0, 1, 256, 50) in (32, 64)
     assert lib.gp_rk45_plan_rows(1, 1, 5, 50) == 16 and lib.gp_rk45_plan_rows(2, 1, 5, 50) == 16  # forward + backward right-hand sides: tiles
     t, n = ctypes.c_int(0), ctypes.c_int(0)
     assert lib.gp_pc_layout(0, 0, 1, 5, 50, ctypes.byref(t), ctypes.byref(n)) == 0 and t.value == 16 | HS and n.value == 21 * 250

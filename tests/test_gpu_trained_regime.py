@@ -242,26 +242,55 @@ def test_accuracy_proxy_within_half_a_point(eval_single):
     sb, eb = _agent("score", encoder_precision="bf16x3"), _agent("energy", encoder_precision="bf16x3")
     bf = [_hip_batch(sb, eb, torch.from_numpy(d["pts"][256 * b:256 * (b + 1)]).cuda(), eval_single["priors"][b]) for b in range(nb)]
     rows.append(("HIP path, encoder_precision='bf16x3' (opt-in), shared draws", _proxy(d, cat("sorted_RTs", bf), cat("sorted_energy", bf))))
-    # PC-100 sampler: fp32 and the opt-in split-bf16 PC step, the same injected noise
+    # PC sampler, 100 steps (the benched sampler), first 256 instances: fp32, the opt-in split-bf16 PC step and the oracle on the same injected
+    # noise.  NOTE what the number says: the reference's predictor step is `mean_x = x + (drift - g^2 grad) * step_size` with step_size =
+    # t_0 - t_1 > 0 (samplers.py:146-148) - it moves AGAINST the score - so its PC sampler does not concentrate on the modes of a trained
+    # model; the reference evaluates with the ODE sampler (scripts/eval_single.sh).  Reproduced as written: HIP == oracle (asserted to the
+    # PC-100 tolerance in test_config1_batch_pc100_trained), and both score about zero here.
     n = 100
     gen = torch.Generator().manual_seed(99)
-    runs = {"f32": [], "bf16x3": []}
-    for b in range(nb):
-        pts = torch.from_numpy(d["pts"][256 * b:256 * (b + 1)]).cuda()
-        prior = torch.randn(256 * K, 9, generator=gen)
-        z = (torch.randn(n, 256 * K, 9, generator=gen).cuda(), torch.randn(n, 256 * K, 9, generator=gen).cuda())
-        for prec in runs:
-            ag = _agent("score", "pc", n, sampler_precision=prec)
-            ag.net.prior_fn = lambda shape, T=1.0: prior * float(go.ve_sigma(1.0))
-            from genpose_amd import reward
-            from genpose_amd.runner import make_batch_sample
-            sample = make_batch_sample(pts)
-            pred = ag.pred_func(data=sample, repeat_num=K, save_path=None, noise=z)
-            energy = ea.get_energy(data=sample, pose_samples=pred, T=1e-5)
-            r = reward.rank_aggregate(pred, energy, ratio=RATIO)
-            runs[prec].append({"sorted_RTs": rotation.pose9_to_RT(r["sorted_poses"]).cpu(), "sorted_energy": r["sorted_energy"].cpu()})
-    rows.append(("HIP path, PC sampler 100 steps, fp32", _proxy(d, cat("sorted_RTs", runs["f32"]), cat("sorted_energy", runs["f32"]))))
-    rows.append(("HIP path, PC sampler 100 steps, sampler_precision='bf16x3' (opt-in)", _proxy(d, cat("sorted_RTs", runs["bf16x3"]), cat("sorted_energy", runs["bf16x3"]))))
+    from genpose_amd import reward
+    from genpose_amd.runner import make_batch_sample
+    d0 = {k: v[:256] for k, v in d.items()}
+    pts0 = torch.from_numpy(d["pts"][:256])
+    prior = torch.randn(256 * K, 9, generator=gen)
+    z1, z2 = torch.randn(n, 256 * K, 9, generator=gen), torch.randn(n, 256 * K, 9, generator=gen)
+    zdev = (z1.cuda(), z2.cuda())
+    pc = {}
+    for prec in ("f32", "bf16x3"):
+        ag = _agent("score", "pc", n, sampler_precision=prec)
+        ag.net.prior_fn = lambda shape, T=1.0: prior * float(go.ve_sigma(1.0))
+        sample = make_batch_sample(pts0.cuda())
+        pred = ag.pred_func(data=sample, repeat_num=K, save_path=None, noise=zdev)
+        energy = ea.get_energy(data=sample, pose_samples=pred, T=1e-5)
+        r = reward.rank_aggregate(pred, energy, ratio=RATIO)
+        pc[prec] = _proxy(d0, rotation.pose9_to_RT(r["sorted_poses"]).cpu().numpy(), r["sorted_energy"].cpu().numpy())
+    sd, sde = _sd("score"), _sd("energy")
+    feat_r = eval_single["ora"][0]["feat"].repeat_interleave(K, 0)
+    cen_r = pts0.mean(dim=1).repeat_interleave(K, 0)
+    with _host_threads():
+        _, xo = go.pc_sampler(lambda x, t: go.score_forward(sd, feat_r, x, t), prior * float(go.ve_sigma(1.0)), cen_r, n, z1, z2)
+        pose = xo.clone().float()
+        pose[:, -3:] -= cen_r
+        feat_e = torch.from_numpy(opar.encoder_features("energy", pts0, ckpt=CKPT["energy"])).repeat_interleave(K, 0)
+        eo = go.energy_forward(sde, feat_e, pose, torch.ones(256 * K, 1) * 1e-5).reshape(256, K, 2)
+    so, seo = go.sort_poses_by_energy(xo.reshape(256, K, 9), eo)
+    rows.append(("PC sampler 100 steps, first 256: HIP path fp32", pc["f32"]))
+    rows.append(("PC sampler 100 steps, first 256: CPU oracle, the same draws", _proxy(d0, go.pose9_to_RT(so), seo.numpy())))
+    rows.append(("PC sampler 100 steps, first 256: HIP sampler_precision='bf16x3' (opt-in)", pc["bf16x3"]))
+    # how far apart are the AGGREGATED poses of the two implementations, measured the way the metric measures (sgpa_utils.py:548-560): the full
+    # rotation for camera / laptop / mug, the direction of the y axis for the categories that are symmetric about it (their candidates spread
+    # around the axis, the quaternion mean's top eigenvector is then near-degenerate in the spin - which the metric ignores)
+    ang, shift = [], []
+    for b, (h, o) in enumerate(zip(eval_single["hip"], eval_single["ora"])):
+        Rh = rotation.quaternion_to_matrix(h["avg_pose"][:, :4].double()).numpy()
+        Ro = rotation.quaternion_to_matrix(o["avg_qt"][:, :4].double()).numpy()
+        sym = np.isin(d["cat"][256 * b:256 * (b + 1)], (0, 1, 3))
+        cos_full = np.clip((np.trace(Rh @ Ro.transpose(0, 2, 1), axis1=1, axis2=2) - 1) / 2, -1, 1)
+        cos_y = np.clip(np.sum(Rh[:, :, 1] * Ro[:, :, 1], axis=1), -1, 1)
+        ang.append(np.degrees(np.arccos(np.where(sym, cos_y, cos_full))))
+        shift.append(np.linalg.norm(h["avg_pose"][:, 4:].numpy().astype(np.float64) - o["avg_qt"][:, 4:].numpy().astype(np.float64), axis=1) * 1000)
+    ang, shift = np.concatenate(ang), np.concatenate(shift)
     keys = ["5deg2cm", "5deg5cm", "10deg2cm", "10deg5cm", "10deg10cm"]
     lines = [f"accuracy proxy: {256 * nb} held-out synthetic instances (synth.make_posed_cloud {HELD_OUT}..), K = {K}, ODE T0 = {T0} unless stated, "
              f"top {int(RATIO * 100)} % by energy averaged; evaluation.compute_mAP, mean AP over the six categories, percent",
@@ -269,10 +298,19 @@ def test_accuracy_proxy_within_half_a_point(eval_single):
     for name, s in rows:
         lines.append(f"{name:72s}" + "".join(f"{s[k]:11.2f}" for k in keys))
     delta = {k: hip[k] - ora[k] for k in keys}
-    lines.append(f"{'HIP - oracle (shared draws)':72s}" + "".join(f"{delta[k]:+11.2f}" for k in keys))
+    lines.append(f"{'HIP - oracle (ODE, shared draws)':72s}" + "".join(f"{delta[k]:+11.2f}" for k in keys))
+    lines.append(f"aggregated pose, HIP vs oracle on shared draws ({len(ang)} instances): rotation apart median {np.median(ang):.2e} deg, p99 {np.quantile(ang, 0.99):.2e}, max {ang.max():.2e} deg "
+                 f"(y axis only for the symmetric categories, as the metric measures); translation apart median {np.median(shift):.2e} mm, p99 {np.quantile(shift, 0.99):.2e}, "
+                 f"max {shift.max():.2e} mm")
+    lines.append("PC rows: the reference's predictor step moves against the score (samplers.py:146-148, sign as written, reproduced) - its PC sampler does "
+                 "not concentrate on the modes of a trained model; the reference evaluates with the ODE sampler.")
     print("\n".join(lines))
     if REPORT:
         with open(REPORT, "w") as f:
             f.write("\n".join(lines) + "\n")
     assert abs(delta["5deg5cm"]) <= 0.5, delta
     assert all(abs(v) <= 1.0 for v in delta.values()), delta
+    # degrees / millimetres.  A candidate at the top-60 % boundary whose energy differs by 5e-4 between the implementations may be selected on one
+    # side only: the aggregate then moves by 1/30 of the distance between two candidates - hence a bound on the 99th percentile and a looser one on the maximum
+    assert np.quantile(ang, 0.99) < 0.5 and ang.max() < 3.0 and np.quantile(shift, 0.99) < 1.0 and shift.max() < 5.0, (ang.max(), shift.max())
+    assert abs(pc["f32"]["10deg10cm"] - rows[-2][1]["10deg10cm"]) <= 1.0
