@@ -529,7 +529,7 @@ def tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend):
             per.append((time.perf_counter() - t0) / nf)
         dt1 = statistics.median(per)
         single = {"ms_per_frame": round(dt1 * 1e3, 3), "ms_per_frame_min": round(min(per) * 1e3, 3), "ms_per_frame_max": round(max(per) * 1e3, 3),
-                  "repeats": len(per), "frames_per_repeat": nf, "statistic": "median of the repeats",
+                  "repeats": len(per), "frames_per_repeat": nf, "statistic": "median of the repeats", "ms_per_frame_by_repeat": [round(v * 1e3, 3) for v in per],
                   "frames_per_s": round(1.0 / dt1, 1), "objects_per_frame": n_obj, "nfev": int(sa.net.last_sampler.last_stats["nfev"]),
                   "workload": "one sequence, one TrackingRunner.step per frame"}
     if rank == 0:
@@ -888,7 +888,8 @@ def config0_leg(torch, dev):
             per.append((time.perf_counter() - t0) / nb)
         dt = statistics.median(per)
         out[name] = {"ms_per_call": round(dt * 1e3, 3), "ms_per_call_min": round(min(per) * 1e3, 3), "ms_per_call_max": round(max(per) * 1e3, 3),
-                     "repeats": reps, "calls_per_repeat": nb, "statistic": "median of the repeats", "poses_per_s": round(B / dt, 1)}
+                     "repeats": reps, "calls_per_repeat": nb, "statistic": "median of the repeats", "ms_per_call_by_repeat": [round(v * 1e3, 3) for v in per],
+                     "poses_per_s": round(B / dt, 1)}
         if sampler == "ode":
             out[name]["nfev"] = int(sa.net.last_sampler.last_stats["nfev"])
     return out

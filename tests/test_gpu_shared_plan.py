@@ -101,3 +101,32 @@ def test_plan_queries_of_the_c_boundary():
         assert L.gp_rk45_partials_count(0, 48 | SHARED, 1, 64, 50) == -1 and L.gp_rk45_partials_count(1, 48 | SHARED, 1, 256, 50) == -1
         # the energy model's score and the likelihood ODE never take it
         assert L.gp_rk45_plan_rows(1, 1, 256, 50) in (16, 128) and L.gp_rk45_plan_rows(2, 1, 256, 50) in (16, 128)
+
+
+def test_shared_chunk_plan_beside_a_busy_stream(snet):
+    """The hand-over inside the launch must not depend on all 256 workgroups being resident at once: with another stream's kernels owning CUs
+    (an encoder pass of 256 clouds: persistent workgroups on every CU) the attempt's workgroups start in waves, a consumer of a shared chunk
+    waits (bounded) for a producer that has a LOWER workgroup index - dispatched before it - and the result must be the undisturbed run's,
+    bit for bit, with no solve failing on the bounded wait."""
+    from genpose_amd import synth
+    from genpose_amd.encoder import Pointnet2EncoderHIP
+    from genpose_amd.samplers import ODESampler
+    B, K = 256, 50
+    cvec, centre, x0 = _inputs(B, K, 5)
+    smp = ODESampler(snet, B, K, "cuda")
+    if not smp.shared:
+        pytest.skip("shared-chunk plan does not apply on this device")
+    (_, quiet), sq = _solve(smp, cvec, centre, x0)
+    quiet = quiet.clone()
+    enc = Pointnet2EncoderHIP(go.make_state_dict(0, "score"), "cuda")
+    big = torch.from_numpy(synth.make_batch(256, start=5000)).cuda()
+    side = torch.cuda.Stream()
+    enc.forward(big)
+    torch.cuda.synchronize()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                enc.forward(big)  # ~15 ms of kernels that fill every CU, underneath the 14 ms solve
+        (_, got), sg = _solve(smp, cvec, centre, x0)
+        assert sg == sq and torch.equal(got, quiet), f"solve {rep} beside a busy stream"
+    torch.cuda.synchronize()
