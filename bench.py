@@ -192,6 +192,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the host driver only supports dmabuf IPC: without this RCCL's first exchange between processes fails with `hipIpcGetMemHandle: invalid
+    # argument` (already exported on the boxes this runs on; set here too so that a bare launcher environment cannot lose it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     guard = _StartGuard(args, rank, world)
     if world > 1:
         guard.watch_sigterm()  # from the first moment on: a peer may die while this rank is still importing torch
