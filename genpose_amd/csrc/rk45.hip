@@ -158,7 +158,7 @@ __device__ __forceinline__ void stx(double *p, double v) {
 // was written by other workgroups: the stages of an attempt are separate launches under this plan.
 // XWG / wg_tile / wg_part (shared-chunk plan): the tile and the partial-sum slot come from the caller instead of blockIdx.x, and XWG marks a
 // tile whose state other workgroups of the same launch have written or will read (ldx / stx above).
-template <int P, int STAGE, int MODEL, bool SPLIT = false, bool XWG = false>
+template <int P, int STAGE, int MODEL, bool SPLIT = false, bool XWG = false, bool ORD8 = false>
 __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_scorenet &net, float *lds, double *sh, int wg_tile = -1, int wg_part = -1) {
     static_assert(MODEL == 0 || P == gp_bwd::DP, "the backward pass runs on 16-row tiles");
     static_assert(!SPLIT || (MODEL == 0 && P == 16), "head-split: score model, 16-row tiles");
@@ -219,7 +219,8 @@ __device__ __forceinline__ bool rk45_stage_body(const OdeArgs &a, const gp_score
     const float *F;
     int ldf;
     if constexpr (MODEL == 0) {
-        trunk_ftheta<P, false, TrunkNoEmit, SPLIT>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre, TrunkNoEmit(), hsel);
+        // (ORD8: the shared-chunk plan's tiles - the output sums in the order of the 32- / 64-row tiles, score_trunk.h)
+        trunk_ftheta<P, false, TrunkNoEmit, SPLIT, ORD8 || P == 48>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre, TrunkNoEmit(), hsel);
         F = lds + L::OFF_H1, ldf = L::LDH;
     } else {
         F = gp_bwd::score_vjp_tile<MODEL == 1 ? gp_bwd::ENERGY : gp_bwd::SCORE_DIV>(lds, net, a.cvec, tvec, row0, rend, a.kcand, pre, sigma);
@@ -349,28 +350,28 @@ __global__ __launch_bounds__(TrunkCfg<PW>::NT) void rk45_attempt_shared_kernel(O
     if (has_x && xs == S && alive) {                                                                        \
         if (S > 1) alive = shared_chunk_wait(flag, epoch + S - 1, st, sh);                                  \
         if (alive) {                                                                                        \
-            rk45_stage_body<16, S, 0, false, true>(a, net, lds, sh, xtile, xpart);                          \
+            rk45_stage_body<16, S, 0, false, true, true>(a, net, lds, sh, xtile, xpart);                          \
             shared_chunk_signal(flag, epoch + S);                                                           \
             __syncthreads();                                                                                \
         }                                                                                                   \
     }
     GP_SHARED_UNIT(1)
-    rk45_stage_body<PW, 1, 0>(a, net, lds, sh, wg, wg);
+    rk45_stage_body<PW, 1, 0, false, false, true>(a, net, lds, sh, wg, wg);
     __syncthreads();
     GP_SHARED_UNIT(2)
-    rk45_stage_body<PW, 2, 0>(a, net, lds, sh, wg, wg);
+    rk45_stage_body<PW, 2, 0, false, false, true>(a, net, lds, sh, wg, wg);
     __syncthreads();
     GP_SHARED_UNIT(3)
-    rk45_stage_body<PW, 3, 0>(a, net, lds, sh, wg, wg);
+    rk45_stage_body<PW, 3, 0, false, false, true>(a, net, lds, sh, wg, wg);
     __syncthreads();
     GP_SHARED_UNIT(4)
-    rk45_stage_body<PW, 4, 0>(a, net, lds, sh, wg, wg);
+    rk45_stage_body<PW, 4, 0, false, false, true>(a, net, lds, sh, wg, wg);
     __syncthreads();
     GP_SHARED_UNIT(5)
-    rk45_stage_body<PW, 5, 0>(a, net, lds, sh, wg, wg);
+    rk45_stage_body<PW, 5, 0, false, false, true>(a, net, lds, sh, wg, wg);
     __syncthreads();
     GP_SHARED_UNIT(6)
-    rk45_stage_body<PW, 6, 0>(a, net, lds, sh, wg, wg);
+    rk45_stage_body<PW, 6, 0, false, false, true>(a, net, lds, sh, wg, wg);
 #undef GP_SHARED_UNIT
 }
 

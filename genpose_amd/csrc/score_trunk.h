@@ -43,7 +43,7 @@ struct TrunkLds {
     static constexpr bool COMPACT = P >= 32, INPLACE = COMPACT && !KEEP;
     static constexpr int LD0 = 16 + GP_LD_PAD, LDH = HID + GP_LD_PAD, LDC = HEADS + 16, NCLD = trunk_staged_clouds<P>();
     static constexpr int OFF_H1 = P * LD0, OFF_H2 = INPLACE ? OFF_H1 : OFF_H1 + P * LDH, OFF_RED = OFF_H2 + P * LDH,
-                         NRED = (COMPACT ? 1 : 4) * TrunkCfg<P>::NW,
+                         NRED = P == 48 ? 8 : (COMPACT ? 1 : 4) * TrunkCfg<P>::NW,  // (48 rows: four waves park the eight partials of ORDER8 below)
                          OFF_WOUT = OFF_RED + NRED * P * 12, OFF_CVT = OFF_WOUT + POSE * HID,
                          TOTAL = OFF_CVT + NCLD * LDC;
 };
@@ -205,11 +205,18 @@ struct TrunkNoEmit {};
 // served by three workgroups on three CUs, each streaming half the weights (0.5 MB instead of 1 MB) and issuing half the MFMAs; only
 // components 3 hsel .. 3 hsel + 2 of f_theta are produced (the others are left untouched in H1).  Same MFMA sequence per accumulator, same
 // combine order per component: the components a workgroup produces are bit-identical to the unsplit tile's.
-template <int P, bool KEEP_H1 = false, class Emit = TrunkNoEmit, bool SPLIT = false>
+// ORDER8 (four-wave tiles: 16 rows on request, 48 rows always): the 256 -> 3 output sums are formed in the ORDER of the eight-wave compact
+// tiles (32 / 64 rows) - per head, wave w of eight adds the contributions of chunks w and w + 8, its four lane groups are combined as
+// (g0 + g1) + (g2 + g3), the eight wave partials are added in wave order.  A four-wave tile owns chunks w, w + 4, w + 8, w + 12 per wave:
+// it keeps TWO running sums (chunks w, w + 8 -> "wave" w; chunks w + 4, w + 12 -> "wave" w + 4), reduces each over the lane groups and
+// parks eight partials.  Same products, same additions in the same order: the tile's f_theta equals the 32- / 64-row tiles' BIT FOR BIT,
+// which is what lets the RK45 driver's shared-chunk plan (48-row own tiles + 16-row shared tiles) return the whole-tile plans' poses.
+template <int P, bool KEEP_H1 = false, class Emit = TrunkNoEmit, bool SPLIT = false, bool ORDER8 = (P == 48)>
 __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net, const float *__restrict__ cvec, const float *__restrict__ tvec,
                                              int row0, int nrows, int kcand, TrunkPre<P> &pre, Emit emit = Emit(), int hsel = 0) {
     using L = TrunkLds<P, KEEP_H1>;
     constexpr int PT = P / 16, NW = TrunkCfg<P>::NW, NV = TrunkCfg<P>::NV, NT = TrunkCfg<P>::NT;
+    static_assert(!ORDER8 || (NW == 4 && NV == 4 && L::NRED >= 8 && !SPLIT), "ORDER8: a four-wave tile reproducing the eight-wave order");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *X0 = lds, *H1 = lds + L::OFF_H1, *H2 = lds + L::OFF_H2, *red = lds + L::OFF_RED;
     const int ncl[4] = {wave, wave + NW, wave + 2 * NW, wave + 3 * NW};
@@ -247,13 +254,17 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
         // next head's first weight stages are requested before this head runs (hides the cold start)
         if (!SPLIT && h < 2) mfma_preload<NV>(stH[(h + 1) & 1], net.w_headx, HID / 16, HEADS / 16, nch[h + 1]);
         mfma_run<NV, PT>(stH[h & 1], H2, L::LDH, 0, net.w_headx, HID / 16, HEADS / 16, nch[h], acc);
-        float part[PT][3];  // [p-chunk][component], this wave's n-chunks of head h
+        constexpr int NPS = ORDER8 ? 2 : 1;  // running sums per (p-chunk, component): ORDER8 keeps the even and the odd chunks apart
+        float part[NPS][PT][3];  // [sum][p-chunk][component], this wave's n-chunks of head h
 #pragma unroll
-        for (int p = 0; p < PT; ++p) part[p][0] = part[p][1] = part[p][2] = 0.f;
+        for (int e = 0; e < NPS; ++e)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) part[e][p][0] = part[e][p][1] = part[e][p][2] = 0.f;
         HeadOps<PT, NV> o;
         head_ops_load<P, PT, NV, KEEP_H1>(o, lds, pre.staged, cvec, tvec, hh, nch[h], cloud, pre.cloud0);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
+            const int e = ORDER8 ? (i & 1) : 0;
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
                 f32x4 v = acc[i][p] + o.cv[i][p];
@@ -262,29 +273,33 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
                 v.z = fmaxf(v.z, 0.f);
                 v.w = fmaxf(v.w, 0.f);
                 if constexpr (!__is_same(Emit, TrunkNoEmit)) emit(hh, i, p, v, o.w0[i], o.w1[i], o.w2[i], nch[h][i] * 16 + 4 * (lane >> 4));
-                part[p][0] += v.x * o.w0[i].x + v.y * o.w0[i].y + v.z * o.w0[i].z + v.w * o.w0[i].w;
-                part[p][1] += v.x * o.w1[i].x + v.y * o.w1[i].y + v.z * o.w1[i].z + v.w * o.w1[i].w;
-                part[p][2] += v.x * o.w2[i].x + v.y * o.w2[i].y + v.z * o.w2[i].z + v.w * o.w2[i].w;
+                part[e][p][0] += v.x * o.w0[i].x + v.y * o.w0[i].y + v.z * o.w0[i].z + v.w * o.w0[i].w;
+                part[e][p][1] += v.x * o.w1[i].x + v.y * o.w1[i].y + v.z * o.w1[i].z + v.w * o.w1[i].w;
+                part[e][p][2] += v.x * o.w2[i].x + v.y * o.w2[i].y + v.z * o.w2[i].z + v.w * o.w2[i].w;
             }
         }
-        if constexpr (L::COMPACT) {
-            // the 4 channel groups of the wave are summed in registers, one partial per wave is parked
+        if constexpr (L::COMPACT || ORDER8) {
+            // the 4 channel groups of the wave are summed in registers, one partial per (virtual) wave is parked
 #pragma unroll
-            for (int p = 0; p < PT; ++p)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) part[p][c] = lane_groups_sum(part[p][c]);
-            if (lane < 16) {
+            for (int e = 0; e < NPS; ++e)
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) red[(wave * P + p * 16 + lane) * 12 + 3 * hh + c] = part[p][c];
+                    for (int c = 0; c < 3; ++c) part[e][p][c] = lane_groups_sum(part[e][p][c]);
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < NPS; ++e)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) red[((wave + 4 * e) * P + p * 16 + lane) * 12 + 3 * hh + c] = part[e][p][c];
             }
         } else {
             // every lane parks its partial sums; the 4 channel groups x NW waves are combined below in a fixed order
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) red[((wave * 4 + (lane >> 4)) * P + p * 16 + (lane & 15)) * 12 + 3 * hh + c] = part[p][c];
+                for (int c = 0; c < 3; ++c) red[((wave * 4 + (lane >> 4)) * P + p * 16 + (lane & 15)) * 12 + 3 * hh + c] = part[0][p][c];
         }
     }
     __syncthreads();
@@ -297,7 +312,7 @@ __device__ __forceinline__ void trunk_ftheta(float *lds, const gp_scorenet &net,
             if (SPLIT && j / 3 != hsel) continue;  // (uniform control flow is not needed below: the barrier follows the loop)
             float v = 0.f;
 #pragma unroll
-            for (int q = 0; q < L::NRED; ++q) v += red[(q * P + r) * 12 + j];
+            for (int q = 0; q < (ORDER8 ? 8 : L::NRED); ++q) v += red[(q * P + r) * 12 + j];
             if constexpr (KEEP_H1)
                 X0[r * L::LD0 + 12 + j] = v + pre.bout[it];  // x sits in columns 0..8; 12..20 are padding by now
             else

@@ -380,7 +380,8 @@ int gp_rk45_phase_grouped(int phase, int ngroups, int nclouds_per_group, int k, 
  * of scripts/eval_single.sh's batches (800 chunks on 256 CUs).  An attempt is ONE launch of C workgroups: each owns T / C whole chunks for
  * all six stages, and the 6 x (T mod C) (chunk, stage) units of the left-over chunks are dealt out one per workgroup, so the busiest CU
  * evaluates 6 x (T / C) + 1 chunk-stages per attempt instead of 6 x (T / C + 1) (csrc/rk45.hip: rk45_attempt_shared_kernel).  The other
- * phases run on the whole-tile plan.  Results: the per-row arithmetic of every other plan; the error norm's partial sums in another order. */
+ * phases run on the whole-tile plan.  Results: every row's right-hand side is the 32- / 64-row tile plans' bit for bit (the four-wave tiles form
+ * the output sums in their order, score_trunk.h ORDER8); the error norm's partial sums add in another order (poses within 1e-13 of theirs). */
 #define GP_PLAN_SHARED 0x200
 int gp_plan_headsplit_pays(int ntiles16); /* 1 while three workgroups per 16-row tile still get a CU each */
 /* The plan the driver recommends for a launch (may carry GP_PLAN_HEADSPLIT / GP_PLAN_SHARED) and the number of doubles `partials` must hold

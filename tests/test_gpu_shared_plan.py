@@ -3,7 +3,8 @@ attempt, the 16-row chunks that do not divide over the CUs handed from workgroup
 the plan scripts/eval_single.sh's batch shape takes (256 clouds x 50 candidates = 800 chunks on 256 CUs).
 
 Checked: it is what the sampler picks at that shape (and only where it applies); against the whole-tile plans on the same inputs - same
-accept / reject sequence, same evaluation count, poses; repeatable bit for bit (the hand-over is ordered, not racy); the trajectory record;
+accept / reject sequence, same evaluation count, poses to 1e-5 (observed 1e-13: every row's arithmetic is the whole-tile plans' bit for bit,
+only the error norm's partial sums add in another order); repeatable bit for bit (the hand-over is ordered, not racy); the trajectory record;
 the 16-row-own-tile variant (4 097 - 4 768 rows); the sizing query and the plan-0 contract of the C boundary.  Against the CPU oracle the
 shape runs in tests/test_gpu_fullsize.py::test_drop_in_eval_single_as_timed and tests/test_gpu_trained_regime.py."""
 import ctypes
@@ -59,10 +60,14 @@ def test_shared_chunk_plan_against_whole_tiles(snet, B, K, own, other):
     assert np.isfinite(xa).all()
     d_rot, d_tr = np.abs(xa[:, :6] - xb[:, :6]).max(), np.abs(xa[:, 6:] - xb[:, 6:]).max() / np.abs(xb[:, 6:]).max()
     print(f"{B} x {K}: shared-chunk plan {own} vs whole tiles {other}: nfev {sa[0]} / {sb[0]}, max rotation diff {d_rot:.2e}, translation (rel) {d_tr:.2e}")
-    assert d_rot < 2e-4 and d_tr < 2e-4
+    # The four-wave tiles of this plan form the 256 -> 3 output sums in the ORDER of the eight-wave 32- / 64-row tiles (score_trunk.h: ORDER8), so
+    # every row's right-hand side is the whole-tile plans' bit for bit; what remains is the order in which the error norm's partial sums are
+    # added (a step size that differs in its last bit): two WHOLE-tile plans of one problem differ by the same 1e-15 .. 1e-6
+    # (scratch/shared_plan_control.py: 64- vs 32-row tiles median 0, max 3.7e-6 over 100 inputs; this plan vs 32-row tiles max 8.5e-14)
+    assert d_rot < 1e-5 and d_tr < 1e-7, (d_rot, d_tr)
     # the rows of the SHARED chunks in particular (they are the ones that cross workgroups): same bound, looked at on their own
     first_shared = ncu * own
-    assert np.abs(xa[first_shared:, :6] - xb[first_shared:, :6]).max() < 2e-4
+    assert np.abs(xa[first_shared:, :6] - xb[first_shared:, :6]).max() < 1e-5
     # repeatable bit for bit - also through the graph replays of the steady state
     for _ in range(3):
         (_, xr), sr = _solve(a, cvec, centre, x0)
@@ -81,9 +86,9 @@ def test_shared_chunk_plan_records_the_trajectory(snet):
         (pa, xa), sa = _solve(a, cvec, centre, x0, **kw)
         (pb, xb), sb = _solve(b, cvec, centre, x0, **kw)
         assert sa[0] == sb[0] and pa.shape == pb.shape
-        np.testing.assert_allclose(pa.cpu().numpy()[..., :6], pb.cpu().numpy()[..., :6], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(pa.cpu().numpy()[..., :6], pb.cpu().numpy()[..., :6], rtol=0, atol=1e-5)
         scale = float(pb[..., 6:].abs().max())
-        np.testing.assert_allclose(pa.cpu().numpy()[..., 6:], pb.cpu().numpy()[..., 6:], rtol=0, atol=2e-4 * scale)
+        np.testing.assert_allclose(pa.cpu().numpy()[..., 6:], pb.cpu().numpy()[..., 6:], rtol=0, atol=1e-7 * scale)
 
 
 def test_plan_queries_of_the_c_boundary():
