@@ -169,3 +169,24 @@ def test_a_rank_that_dies_before_the_rendezvous_still_yields_a_line(launcher):
     assert line["launch"]["rank"] == 0 and line["launch"]["backend"] in ("gloo", None) and line["launch"]["world_size_env"] == 2, line
     assert took < 120, took  # seconds, not the driver's 1 800 s limit
     print(f"killed-rank rehearsal ({launcher}): line after {took:.0f} s: {line['error']}")
+
+
+def test_more_ranks_than_devices_yields_a_line():
+    """The real RCCL start path with a rank that cannot get a device (two ranks on this one-GPU box, no GP_BENCH_ONE_DEVICE): rank 1 reports
+    'LOCAL_RANK 1 but torch sees 1 device(s)' and leaves; rank 0 is inside init_process_group('nccl') waiting for it when the launcher
+    terminates it - and still prints its one line."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("written for a one-GPU box")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GP_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    env["GP_BENCH_START_TIMEOUT"] = "30"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == 2 and "error" in line and line["launch"]["rank"] == 0, line
+    assert line["launch"]["backend"] in ("nccl", None) and line["launch"]["device_count"] == 1, line
+    assert "LOCAL_RANK 1 but torch sees 1 device(s)" in p.stderr
