@@ -220,7 +220,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = guard.backend = "gloo" if one_dev else "nccl"  # "nccl" = RCCL on ROCm
-        limit = float(os.environ.get("GP_BENCH_START_TIMEOUT", "180"))
+        limit = float(os.environ.get("GP_BENCH_START_TIMEOUT", "600"))  # (the first `import torch` on a fresh box takes minutes and differs between ranks)
         if world == 1:
             guard.watch_sigterm()
         guard.arm(limit + 30, f"process group start ({backend}, {world} ranks)")

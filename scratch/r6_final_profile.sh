@@ -48,4 +48,8 @@ F64=$(find /tmp/pmc_fetch_64 -name "*.db" | head -1); W64=$(find /tmp/pmc_write_
 F640=$(find /tmp/pmc_fetch_640 -name "*.db" | head -1); W640=$(find /tmp/pmc_write_640 -name "*.db" | head -1)
 python scratch/pmc_traffic.py $O/pmc_traffic.json 64:$F64:$W64 640:$F640:$W640 > $O/pmc_traffic.log 2>&1; tail -12 $O/pmc_traffic.log
 python scratch/pmc_summary.py $(find /tmp/pmc_sq_640 -name "*.db" | head -1) > $O/pmc_sq_summary.txt 2>&1
+# the RK45 attempt at the eval_single shape under its three plans: SQ counters of rk45_attempt_shared_kernel<48> against the stage kernels
+timeout 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace -d /tmp/pmc_sq_ode -o run -- python scratch/ode_plan_time.py > $O/pmc_sq_ode.log 2>&1
+{ echo "---- RK45 at 256 clouds x 50 candidates (scratch/ode_plan_time.py): attempt / stage kernels of the three plans"; python scratch/pmc_summary.py $(find /tmp/pmc_sq_ode -name "*.db" | head -1) rk45_; } >> $O/pmc_sq_summary.txt 2>&1
+timeout 300 python scratch/shared_plan_soak.py > $O/shared_plan_soak.txt 2>&1; timeout 200 python scratch/shared_plan_control.py >> $O/shared_plan_soak.txt 2>&1; tail -3 $O/shared_plan_soak.txt
 ls $O
