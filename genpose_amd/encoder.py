@@ -74,8 +74,9 @@ class Pointnet2EncoderHIP:
         wanted the ticket - leaves work on the side stream that reads new_xyz[0] and writes the deeper levels: every writer of the
         grouping buffers waits for it first."""
         pending = ws.pop("_join", None)
-        if pending is not None:
-            torch.cuda.current_stream(self.device).wait_event(pending)
+        if pending:
+            for ev in pending.values():  # {level: event}
+                torch.cuda.current_stream(self.device).wait_event(ev)
 
     # ------------------------------------------------------------------ workspace (cached per batch/size)
     def _workspace(self, B, N, slot=0):
@@ -198,20 +199,24 @@ class Pointnet2EncoderHIP:
         _lib.call("gp_fps_chain_arith", self.arith, B, N, 1, m0, ptr(xyz0), ptr(ws["fps_idx"][0]), ptr(ws["new_xyz"][0]), None, None, None, None, stream_ptr())
         fork = torch.cuda.Event()
         fork.record(cur)
+        joins = {}
         with torch.cuda.stream(self._side):
             self._side.wait_event(fork)
-            rest = group_levels[1:]
-            mr = (ctypes.c_int * 3)(*([cfg["npoints"][k] for k in rest] + [0] * (3 - len(rest))))
-            pi = [ptr(ws["fps_idx"][l + 1]) if l < len(rest) else None for l in range(2)]
-            px = [ptr(ws["new_xyz"][l + 1]) if l < len(rest) else None for l in range(2)]
-            # the deeper levels select among level 0's centres, in their order: the same chain, started from new_xyz[0]
-            _lib.call("gp_fps_chain_arith", self.arith, B, cfg["npoints"][group_levels[0]], len(rest), mr, ptr(ws["new_xyz"][0]), pi[0], px[0], pi[1], px[1], None, None,
-                      stream_ptr())
-            self._ball_queries(ws, xyz0, B, N, levels=set(rest))
-            join = torch.cuda.Event()
-            join.record(self._side)
+            # the deeper levels select among the previous level's centres, in their order (the reference samples new_xyz of the level
+            # before): ONE level per launch, each followed by its ball query and its own join event, so that the set abstraction of level k
+            # starts as soon as ITS centres and neighbourhoods exist - level 1's kernels run beside level 2's sampling (round 6: at 5 clouds
+            # the fused two-level chain held the pass for 97 us of sampling + both ball queries; a level at a time it is 60 us + one)
+            n_src = cfg["npoints"][group_levels[0]]
+            for l, k in enumerate(group_levels[1:]):
+                mk = (ctypes.c_int * 3)(cfg["npoints"][k], 0, 0)
+                _lib.call("gp_fps_chain_arith", self.arith, B, n_src, 1, mk, ptr(ws["new_xyz"][l]), ptr(ws["fps_idx"][l + 1]), ptr(ws["new_xyz"][l + 1]), None, None,
+                          None, None, stream_ptr())
+                self._ball_queries(ws, xyz0, B, N, levels={k})
+                joins[k] = torch.cuda.Event()
+                joins[k].record(self._side)
+                n_src = cfg["npoints"][k]
         self._ball_queries(ws, xyz0, B, N, levels={group_levels[0]})
-        ws["_join"] = join
+        ws["_join"] = joins  # {level: event}
         ws["_grouping_key"] = self.grouping_key()
         return ws
 
@@ -334,10 +339,12 @@ class Pointnet2EncoderHIP:
             zstride = sum(sc.couts[0] for sc in scales)
             if z is not None:
                 _lib.call("gp_point_linear", B * n, cin, zstride, ptr(feats), ptr(self.w.z_weights[k]), ptr(z), st)
-            if k >= 1 and src.get("_join") is not None:
-                # deferred grouping (prepare_grouping(defer_join=True)): the deeper levels' centres and neighbourhoods were computed on
-                # the side stream under level 0 - first use here
-                torch.cuda.current_stream(self.device).wait_event(src.pop("_join"))
+            if k >= 1 and src.get("_join") and k in src["_join"]:
+                # deferred grouping (prepare_grouping(defer_join=True)): this level's centres and neighbourhoods were computed on the
+                # side stream under the levels before it - first use here
+                torch.cuda.current_stream(self.device).wait_event(src["_join"].pop(k))
+                if not src["_join"]:
+                    src.pop("_join")
             off, zoff = 0, 0
             for i, sc in enumerate(scales):
                 (w1, b1), (w2, b2), (w3, b3) = sc.layers
