@@ -541,6 +541,10 @@ def tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend):
                   "mean_nfev_per_frame_by_repeat": [round(v, 1) for v in nfe],
                   "frames_per_s": round(1.0 / dt1, 1), "objects_per_frame": n_obj, "nfev": int(sa.net.last_sampler.last_stats["nfev"]),
                   "workload": "one sequence, one TrackingRunner.step per frame"}
+        try:  # the same loop on the TRAINED checkpoints of tests/golden/trained (a tracker that tracks: the solve takes ~4 attempts per frame)
+            single["trained_weights"] = single_sequence_trained(torch, str(dev), K, T0, n_obj)
+        except Exception as exc:  # noqa: BLE001  (an informative extra must never cost the line)
+            single["trained_weights"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         value = world * S * n_obj * args.steps / elapsed
         flop_per_pose = 2 * (FLOP_ENCODER + FLOP_CLOUD_EMBED) + K * (nfev + 1) * FLOP_SCORE_ROW
@@ -558,6 +562,52 @@ def tracking_bench(torch, args, dist, dev, world, rank, one_dev, backend):
             "launch": {"mode": os.environ.get("GP_BENCH_LAUNCH", "direct" if world == 1 else "torch.distributed.run"),
                        "world_size_observed": (dist.get_world_size() if dist is not None else 1), "backend": backend},
             "whole_path_tflops": round(value * flop_per_pose / 1e12, 2), "roofline": None, "cpu_baseline": None, "single_sequence": single}), flush=True)
+
+
+def single_sequence_trained(torch, dev, K, T0, n_obj):
+    """One tracking sequence frame by frame with the TRAINED score / energy checkpoints (tests/golden/trained, scratch/train_synth.py) on a
+    synthetic sequence with known poses (synth.posed_sequence): what a frame costs when the network actually pulls the candidates into a mode -
+    the seeded random network of the main legs wanders, and its adaptive solve takes 4-8 attempts per frame instead of ~4."""
+    import numpy as np
+    from genpose_amd import synth
+    from genpose_amd.config import get_config
+    from genpose_amd.posenet_agent import PoseNet
+    from genpose_amd.runner import TrackingRunner
+    ck = {m: os.path.join(ROOT, "tests", "golden", "trained", f"ckpt_{m}.pth") for m in ("score", "energy")}
+    sa = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=["ode"]))
+    ea = PoseNet(get_config(device=dev, posenet_mode="energy"))
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):  # (load_ckpt prints the path, like the reference; the line must stay the only stdout)
+        sa.load_ckpt(model_dir=ck["score"], model_path=True, load_model_only=True)
+        ea.load_ckpt(model_dir=ck["energy"], model_path=True, load_model_only=True)
+    nfr = 30
+    seq = synth.posed_sequence(11, n_frames=nfr, n_obj=n_obj)
+    frames = [torch.from_numpy(seq["pts"][f]).to(dev) for f in range(nfr)]
+    gt = torch.eye(4).repeat(n_obj, 1, 1)
+    gt[:, :3, :3], gt[:, :3, 3] = torch.from_numpy(seq["R"][0]).float(), torch.from_numpy(seq["t"][0]).float()
+    names = [f"o{j}" for j in range(n_obj)]
+    tr = TrackingRunner(sa, ea, repeat_num=K, T0=T0)
+    for f in range(8):
+        tr.step(frames[f], names, gt)
+    torch.cuda.synchronize()
+    per, nfe, terr = [], [], []
+    for rep in range(7):
+        tr.reset()  # every repeat is the 30-frame sequence from its first frame
+        t0 = time.perf_counter()
+        evals = 0
+        for f in range(nfr):
+            out = tr.step(frames[f], names, gt)
+            evals += int(sa.net.last_sampler.last_stats["nfev"])
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / nfr)
+        nfe.append(evals / nfr)
+        terr.append(float(np.median(np.linalg.norm(out["average_sRT"][:, :3, 3].cpu().numpy() - seq["t"][nfr - 1], axis=1)) * 100))
+    dt = statistics.median(per)
+    return {"ms_per_frame": round(dt * 1e3, 3), "ms_per_frame_min": round(min(per) * 1e3, 3), "ms_per_frame_max": round(max(per) * 1e3, 3), "repeats": len(per),
+            "frames_per_repeat": nfr, "statistic": "median of the repeats", "mean_nfev_per_frame_by_repeat": [round(v, 1) for v in nfe],
+            "median_translation_error_cm_at_the_last_frame": round(statistics.median(terr), 2), "objects_per_frame": n_obj,
+            "weights": "trained on synthetic posed clouds (tests/golden/trained)", "workload": "synth.posed_sequence(11): 30 frames, one TrackingRunner.step per frame"}
 
 
 def pc_roofline(torch, smp, rows, n, flop_row=FLOP_SCORE_ROW):

@@ -242,6 +242,37 @@ def posed_batch(indices, n_pts=1024):
             "handle_visibility": np.ones(len(items), dtype=np.int64)}
 
 
+def posed_sequence(seed, n_frames=6, n_obj=5, n_pts=1024):
+    """A short synthetic tracking sequence with ground truth: n_obj objects (categories drawn once), each moving smoothly - a few millimetres and
+    about a degree per frame - and re-rendered through the camera model every frame (new visible side, new pixel grid, new resampling).
+    -> dict: pts [F,n_obj,n_pts,3] f32, R [F,n_obj,3,3], t [F,n_obj,3] f64, cat [n_obj] i64."""
+    rng = np.random.default_rng([0x73657175, seed])
+    cats = rng.integers(0, len(CATEGORIES), n_obj)
+    ext = rng.uniform(0.10, 0.28, n_obj)
+    t0 = np.stack([rng.uniform(-0.25, 0.25, n_obj), rng.uniform(-0.25, 0.25, n_obj), rng.uniform(0.6, 1.1, n_obj)], 1)
+    R0 = np.stack([_rand_rot(rng) for _ in range(n_obj)], 0)
+    vel = rng.normal(size=(n_obj, 3)) * 0.003                      # metres per frame
+    axis = rng.normal(size=(n_obj, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    rate = np.deg2rad(rng.uniform(0.5, 1.5, n_obj))                # radians per frame
+    out = {"pts": np.zeros((n_frames, n_obj, n_pts, 3), np.float32), "R": np.zeros((n_frames, n_obj, 3, 3)), "t": np.zeros((n_frames, n_obj, 3)),
+           "cat": cats.astype(np.int64)}
+    for f in range(n_frames):
+        for o in range(n_obj):
+            a, th = axis[o], rate[o] * f
+            Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            Rf = (np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)) @ R0[o]
+            tf = t0[o] + vel[o] * f
+            p, nrm = _posed_surface(rng, int(cats[o]), 12000)
+            p = (p * ext[o]) @ Rf.T + tf
+            vis = np.sum((nrm @ Rf.T) * (-p), axis=1) > 0
+            if vis.sum() >= 8:
+                p = p[vis]
+            out["pts"][f, o] = _through_the_camera(p, rng, False, n_pts)
+            out["R"][f, o], out["t"][f, o] = Rf, tf
+    return out
+
+
 def smoke_batch(B, seed=0, n_pts=1024):
     rng = np.random.default_rng(seed)
     return (rng.normal(size=(B, n_pts, 3)) * 0.05 + np.array([0, 0, 0.8])).astype(np.float32)

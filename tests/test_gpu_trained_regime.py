@@ -314,3 +314,61 @@ def test_accuracy_proxy_within_half_a_point(eval_single):
     # side only: the aggregate then moves by 1/30 of the distance between two candidates - hence a bound on the 99th percentile and a looser one on the maximum
     assert np.quantile(ang, 0.99) < 0.5 and ang.max() < 3.0 and np.quantile(shift, 0.99) < 1.0 and shift.max() < 5.0, (ang.max(), shift.max())
     assert abs(pc["f32"]["10deg10cm"] - rows[-2][1]["10deg10cm"]) <= 1.0
+
+
+def test_tracking_sequence_trained():
+    """The tracking loop (evaluation_tracking.py:262-337: warm start from the previous frame's aggregated pose, ODE from T0 = 0.15, energy
+    ranking, top-60 % aggregation) on TRAINED weights over a synthetic sequence with known poses: every frame of the HIP TrackingRunner (the
+    hipGraph path) against the oracle given the same initial poses and prior draws - initial state, all candidates, evaluation count,
+    aggregated pose - and the tracker must actually track: its aggregated poses stay near the ground truth (with random weights they wander)."""
+    from genpose_amd import rotation, synth
+    from genpose_amd.runner import TrackingRunner, add_noise_to_RT
+    F, n_obj, Kt, T0t = 6, 5, 50, 0.15
+    seq = synth.posed_sequence(3, n_frames=F, n_obj=n_obj)
+    sd, sde = _sd("score"), _sd("energy")
+    tr = TrackingRunner(_agent("score"), _agent("energy"), repeat_num=Kt, T0=T0t)
+    names = [f"obj{o}" for o in range(n_obj)]
+    gen = torch.Generator().manual_seed(12)
+    gt0 = torch.eye(4).repeat(n_obj, 1, 1)
+    gt0[:, :3, :3], gt0[:, :3, 3] = torch.from_numpy(seq["R"][0]).float(), torch.from_numpy(seq["t"][0]).float()
+    sym = np.isin(seq["cat"], (0, 1, 3))
+    rot_err, tr_err, nfevs = [], [], []
+    for f in range(F):
+        pts_cpu = torch.from_numpy(seq["pts"][f])
+        prior = torch.randn(n_obj * Kt, 9, generator=gen)
+        draws = [torch.randn(n_obj, generator=gen), torch.randn(n_obj, 4, generator=gen), torch.randn(n_obj, generator=gen), torch.randn(n_obj, 3, generator=gen)]
+        tr.score_agent.net.prior_fn = lambda shape, T=1.0: prior * float(go.ve_sigma(T))
+        out = tr.step(pts_cpu.cuda(), names, gt0, noise_draws=draws)
+        nfev = int(tr.score_agent.net.last_sampler.last_stats["nfev"])
+        nfevs.append(nfev)
+        # ---- the oracle on this frame, from the initial poses the runner used (frame 0: the jittered ground truth of the same draws)
+        cen = pts_cpu.mean(dim=1)
+        init_x = out["init_x"].cpu().float()
+        if f == 0:
+            jit = add_noise_to_RT(gt0, draws=draws)
+            want = torch.cat([jit[:, :3, 0], jit[:, :3, 1], jit[:, :3, 3] - cen], dim=1)
+            np.testing.assert_allclose(init_x.numpy(), want.numpy(), atol=1e-6)
+        with _host_threads():
+            ref, _, ref_nfev = go.pred_func(sd, pts_cpu, cen, Kt, "ode", prior, T0=T0t, init_x=init_x)
+            ref_e = go.get_energy(sde, pts_cpu, cen, out["pred_pose"].cpu(), T=1e-5)
+        assert abs(nfev - ref_nfev) <= 6, (f, nfev, ref_nfev)
+        got = out["pred_pose"].cpu().numpy()
+        np.testing.assert_allclose(got[..., :6], ref.numpy()[..., :6], rtol=0, atol=ODE_ROT_ATOL, err_msg=f"frame {f}: rotation block")
+        np.testing.assert_allclose(got[..., 6:], ref.numpy()[..., 6:], rtol=0, atol=ODE_RTOL * max(1.0, float(ref[..., 6:].abs().max())), err_msg=f"frame {f}: translations")
+        np.testing.assert_allclose(out["energy"].cpu().numpy(), ref_e.numpy(), rtol=5e-4, atol=5e-4 * float(ref_e.abs().max()))
+        sp, _ = go.sort_poses_by_energy(out["pred_pose"].cpu(), out["energy"].cpu())
+        avg_RT, _ = go.aggregate_sorted(go.pose9_to_RT(sp), ratio=RATIO)
+        np.testing.assert_allclose(out["average_sRT"].cpu().numpy(), avg_RT, atol=5e-4, err_msg=f"frame {f}: aggregated pose")
+        # ---- against the ground truth of the frame
+        Ra = out["average_sRT"][:, :3, :3].cpu().numpy().astype(np.float64)
+        Rg = seq["R"][f]
+        cos_full = np.clip((np.trace(Ra @ Rg.transpose(0, 2, 1), axis1=1, axis2=2) - 1) / 2, -1, 1)
+        cos_y = np.clip(np.sum(Ra[:, :, 1] * Rg[:, :, 1], axis=1), -1, 1)
+        rot_err.append(np.degrees(np.arccos(np.where(sym, cos_y, cos_full))))
+        tr_err.append(np.linalg.norm(out["average_sRT"][:, :3, 3].cpu().numpy() - seq["t"][f], axis=1) * 100)
+    rot_err, tr_err = np.array(rot_err), np.array(tr_err)
+    print(f"trained tracker over {F} frames x {n_obj} objects (categories {[synth.CATEGORIES[c] for c in seq['cat']]}): rotation error vs ground truth per frame "
+          f"(median over objects) {np.round(np.median(rot_err, axis=1), 1).tolist()} deg, translation {np.round(np.median(tr_err, axis=1), 2).tolist()} cm; "
+          f"evaluations per frame {nfevs}")
+    assert np.median(tr_err) < 2.0 and np.median(rot_err) < 15.0, (np.median(rot_err), np.median(tr_err))
+    assert np.median(tr_err[-1]) < 3.0, "the tracker has drifted away by the last frame"
