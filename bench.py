@@ -906,6 +906,35 @@ def drop_in_leg(torch, dev, K, B=256, T0=0.55):
             leg["predictor_one_batch_per_launch"] = {"value": round(B * nb / d1, 2), "ms_per_call": round(d1 / nb * 1e3, 3)}
             leg["agent_over_predictor"] = round(d1 / dt, 4)
         out[name] = leg
+    try:  # the same ODE call sequence on the TRAINED checkpoints and held-out posed clouds (informative; never costs the line)
+        import contextlib
+        import io
+        ck = {m: os.path.join(ROOT, "tests", "golden", "trained", f"ckpt_{m}.pth") for m in ("score", "energy")}
+        sa = PoseNet(get_config(device=dev, posenet_mode="score", sampler_mode=["ode"]))
+        et = PoseNet(get_config(device=dev, posenet_mode="energy"))
+        with contextlib.redirect_stdout(io.StringIO()):
+            sa.load_ckpt(model_dir=ck["score"], model_path=True, load_model_only=True)
+            et.load_ckpt(model_dir=ck["energy"], model_path=True, load_model_only=True)
+        tpool = [torch.from_numpy(synth.posed_batch(range(3_000_000 + B * j, 3_000_000 + B * (j + 1)))["pts"]).to(dev) for j in range(2)]
+
+        def tcall(pts):
+            data = make_batch_sample(pts)
+            pred = sa.pred_func(data=data, repeat_num=K, save_path=None, T0=T0)
+            return reward.rank_aggregate(pred, et.get_energy(data=data, pose_samples=pred, T=1e-5), ratio=0.6)["avg_pose"]
+        for j in range(4):
+            tcall(tpool[j % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(nb):
+            tcall(tpool[j % 2])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = sa.net.last_sampler.last_stats
+        out["ode_T0_0.55_trained_weights"] = {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_call": round(dt / nb * 1e3, 3), "nfev": int(st["nfev"]),
+                                              "attempts": int(st["n_attempts"]), "weights": "trained on synthetic posed clouds (tests/golden/trained)",
+                                              "clouds": "held-out synth.make_posed_cloud instances"}
+    except Exception as exc:  # noqa: BLE001
+        out["ode_T0_0.55_trained_weights"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 
