@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Benchmark of the GenPose inference hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+"""Benchmark of the GenPose inference hot path on MI355X (contract: see the task statement / DESIGN.md §6).
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -35,7 +35,7 @@ FLOP_ENCODER = 2.201e9     # per cloud per encoder pass, the reference's count (
 
 
 def encoder_flops_executed():
-    """FLOPs the encoder EXECUTES per cloud after hoisting the feature half of every first SA layer (DESIGN.md §4.5): once per source
+    """FLOPs the encoder EXECUTES per cloud after hoisting the feature half of every first SA layer (DESIGN.md §4.3): once per source
     point instead of once per (centre, sample) row.  Light config (pointnet2.py:57-66)."""
     levels = [  # (source points n, input channels, [(rows per cloud, c1, c2, c3) per scale])
         (1024, 0, [(512 * 16, 16, 16, 32), (512 * 32, 32, 32, 64)]),

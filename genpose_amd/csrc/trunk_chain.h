@@ -27,7 +27,7 @@
 // Measured (MI355X, 32 000 rows): 137-139 us per launch (0.78-0.79 of the fp32 MFMA peak) against 146.6 us for the 32-row tile form;
 // ring steps run at 0.90-0.92 of the MFMA issue rate (what a bare v_mfma loop with LDS operand reads reaches with one wave per SIMD,
 // scratch/occ/mfma_power.hip), the rest is the prologue (operand requests, ring start-up: 4 %), 250 workgroups on 256 CUs, the
-// sustained clock and the tail.
+// sustained clock and the tail (history in EXPERIMENTS.md §G).
 #pragma once
 #include "score_trunk.h"
 

@@ -25,7 +25,7 @@ def make_batch_sample(pts):
 
 class _one_cpu_thread:
     """Host-side torch ops inside the per-frame loops run single-threaded: a multi-threaded CPU op leaves its OpenMP team spinning
-    next to the HIP runtime's progress thread and the following graph replays stall for tens of milliseconds."""
+    next to the HIP runtime's progress thread and the following graph replays stall for tens of milliseconds (EXPERIMENTS.md §G, the tracking history of DESIGN r5 §8)."""
 
     def __enter__(self):
         self.n = torch.get_num_threads()
