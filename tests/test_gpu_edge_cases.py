@@ -39,6 +39,23 @@ def test_c_abi_rejects_bad_arguments_and_accepts_empty_batches():
     assert l.gp_score_eval(1, 5, ctypes.byref(net), _p(xyz), _p(xyz), _p(xyz), _p(xyz), 7, _p(xyz), st) == -1  # unknown mode
     assert l.gp_pc_tile_rows(2, 3, 10) == -1                                                                   # no tile divides a batch
     assert l.gp_rank_aggregate(0, 50, 30, 0, _p(xyz), _p(xyz), _p(xyz), _p(xyz), _p(idx), _p(xyz), st) == 0
+    # round-6 entry points: the one-launch ranking with the 4x4 forms, the RK45 plan queries
+    assert l.gp_rank_aggregate_rt(0, 50, 30, 0, _p(xyz), _p(xyz), _p(xyz), _p(xyz), _p(idx), _p(xyz), _p(xyz), _p(xyz), st) == 0   # empty batch
+    assert l.gp_rank_aggregate_rt(2, 50, 30, 0, _p(xyz), _p(xyz), None, None, None, None, None, _p(xyz), st) == -1  # an aggregated 4x4 without the aggregate
+    assert l.gp_rank_aggregate_rt(2, 50, 51, 0, _p(xyz), _p(xyz), None, None, None, _p(xyz), None, None, st) == -1   # more selected than candidates
+    assert l.gp_rank_aggregate_rt(2, 0, 0, 0, _p(xyz), _p(xyz), None, None, None, None, None, None, st) == -1        # k = 0
+    assert l.gp_rk45_partials_count(0, 0, 0, 5, 50) == -1 and l.gp_rk45_partials_count(3, 0, 1, 5, 50) == -1           # no group / unknown model
+    assert l.gp_rk45_partials_count(0, 48, 1, 256, 50) == -1 and l.gp_rk45_partials_count(0, 0x200, 1, 256, 50) == -1  # 48 rows only under the shared plan; no tile size
+    assert l.gp_rk45_plan_rows(0, 0, 5, 50) == -1 and l.gp_rk45_plan_rows_unshared(0, 1, 0, 50) == -1
+    # a plan that does not serve the shape is refused by the driver itself (no launch): 48 | GP_PLAN_SHARED on 64 clouds, on two groups, for the energy model
+    st8 = torch.zeros(2 * int(l.gp_rk45_state_bytes()), dtype=torch.uint8, device="cuda")
+    buf = torch.zeros(64 * 50 * 9 * 8, dtype=torch.float64, device="cuda")
+    args = lambda model, plan, groups, per: (model, plan, None, 3, groups, per, 50, ctypes.byref(net), _p(xyz), _p(xyz), _p(xyz), _p(st8), _p(buf), _p(buf), _p(buf),
+                                             _p(buf), None, 0, ctypes.c_double(0.55), ctypes.c_double(1e-5), ctypes.c_double(1e-5), ctypes.c_double(1e-5),
+                                             ctypes.c_double(0.0), 1, 0, _p(buf), None, 0, st)
+    assert l.gp_rk45_phase_model(*args(0, 48 | 0x200, 1, 64)) == -1
+    assert l.gp_rk45_phase_model(*args(0, 48 | 0x200, 2, 128)) == -1
+    assert l.gp_rk45_phase_model(*args(1, 48 | 0x200, 1, 256)) == -1
 
 
 @pytest.mark.parametrize("kind", ["all_identical", "two_points", "collinear_grid"])
