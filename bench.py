@@ -78,6 +78,9 @@ def parse():
                     help="run the encoder of the next launch group on a second HIP stream under the sampler graph of the current one "
                          "(pays off with 1-2 batches per launch; no gain at 5, where both stages fill the chip)")
     ap.add_argument("--no-fps-ahead", action="store_true", help="do not run furthest point sampling of the next launch group on a side stream")
+    ap.add_argument("--sampler-streams", type=int, default=1,
+                    help="launch chains in flight (each on its own HIP stream; implies --overlap): with --batches-per-launch 1 two chains interleave "
+                         "two 64-cloud batches' steps on the chip, every batch still its own chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clouds", type=int, default=64, help="clouds of the CPU-baseline sample (BASELINE.md §3: one 64-cloud batch)")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work the baseline leg may spend")
@@ -312,8 +315,8 @@ def main():
     pipe = None
     if pipelined:
         from genpose_amd.pipeline import PipelinedPCPredictor
-        pipe = PipelinedPCPredictor(score_agent, B, K, n, batches_per_launch=args.batches_per_launch, overlap=args.overlap,
-                                    fps_ahead=not args.no_fps_ahead)
+        pipe = PipelinedPCPredictor(score_agent, B, K, n, batches_per_launch=args.batches_per_launch, overlap=args.overlap or args.sampler_streams > 1,
+                                    fps_ahead=not args.no_fps_ahead, sampler_streams=args.sampler_streams, depth=max(2, args.sampler_streams))
     ode_grouped = args.sampler == "ode" and args.pipeline == "score" and not args.no_pipeline and args.batches_per_launch > 1
     ode_pred = None
     if ode_grouped:
@@ -421,7 +424,8 @@ def main():
                                    + (f"PC sampler {n} steps (NFE={n})" if args.sampler == "pc" else f"ODE sampler RK45 T0={T0} (NFE={nfev})")
                                    + (", ScoreNet only" if energy_agent is None else ", + EnergyNet ranking + top-60% aggregation"),
                        "clouds_per_gpu": B, "candidates": K, "sde_steps": n, "sampler": args.sampler, "pipeline": args.pipeline,
-                       "stream_pipelining": bool(pipelined and args.overlap), "batches_per_launch": G,
+                       "stream_pipelining": bool(pipelined and (args.overlap or args.sampler_streams > 1)), "batches_per_launch": G,
+                       "sampler_streams": args.sampler_streams,
                        "weights": "seeded random (reference state-dict schema)", "parallelism": f"clouds sharded x{world}"},
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "timed_s": round(sum(times), 3), "block_ms_median": round(elapsed * 1e3, 3),
                        "block_ms_min": round(times[0] * 1e3, 3), "block_ms_max": round(times[-1] * 1e3, 3), "statistic": "median block"},
@@ -673,8 +677,11 @@ def one_batch_leg(torch, score_agent, pool, B, K, n):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t1
     r = pc_roofline(torch, p1._sampler(0, 1), B * K, n)
-    return {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "kernel": r["kernel"],
-            "rows_per_launch": B * K, "avg_launch_us": r["avg_launch_us"], "frac": r["frac"]}
+    out = {"value": round(B * nb / dt, 2), "unit": "poses/s", "ms_per_step": round(dt / nb * 1e3, 3), "kernel": r["kernel"],
+           "rows_per_launch": B * K, "avg_launch_us": r["avg_launch_us"], "frac": r["frac"]}
+    # (two launch chains in flight - `--sampler-streams 2` - were re-measured in round 6: 21 k poses/s in a quiet process, 13-20 k inside this one:
+    #  bimodal, not reported; EXPERIMENTS.md section H.6)
+    return out
 
 
 def split_bf16_leg(torch, score_agent, pool, B, K, n, G, dev, sampler_too):

@@ -30,6 +30,14 @@ def test_pipelined_equals_sequential():
         torch.cuda.synchronize()
         for i in range(NB):
             assert torch.equal(got[i], seq[i]), f"batch {i}"
+    # several launch chains in flight (one batch per chain, the chains on separate HIP streams): every batch still gets its own result
+    for streams, depth in ((2, 2), (3, 3)):
+        multi = PipelinedPCPredictor(agent, B, K, n, sampler_streams=streams, depth=depth)
+        for _ in range(2):
+            got_m = multi.run(batches, prior_noise=[p.cuda() for p in priors], noise=noises)
+            torch.cuda.synchronize()
+            for i in range(NB):
+                assert torch.equal(got_m[i], seq[i]), f"{streams} chains in flight, batch {i}"
     # oracle spot check on the first batch
     ref, _, _ = go.pred_func(go.make_state_dict(0, "score"), batches[0].cpu(), batches[0].cpu().mean(dim=1), K, "pc", priors[0],
                              sampling_steps=n, z_langevin=noises[0][0].cpu(), z_predictor=noises[0][1].cpu())
